@@ -1,0 +1,174 @@
+/*
+ * include/mvr.h — C ABI of libmvr_hip.so, the MI355X (gfx950) multi-view renderer.
+ *
+ * This is the drop-in boundary for ONE path of ajhamdi/MVTN: models/renderer.py
+ * MVRenderer.forward (reference lines 173-198) -> render_meshes (65-114) /
+ * render_points (116-151), plus the autograd backward the reference gets from
+ * PyTorch3D (triggered at run_mvtn.py:195).  The reference is Python and binds its
+ * renderer by importing PyTorch3D; a maintainer replaces those imports with the
+ * ctypes stub shown in INTEGRATION.md, which calls exactly these entry points.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless marked "host";
+ *   - plain pointers and sizes only: no torch / HIP types in any signature;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call
+ *     only ENQUEUES work on it and returns — no allocation, no synchronisation;
+ *   - flat view index n = b * n_views + v  (util.py:509-521 batch_tensor as used at
+ *     models/renderer.py:79-80), N = n_meshes * n_views;
+ *   - matrices are row-major; R (N,3,3) holds the camera axes as columns and
+ *     X_view = X_world * R + T  (PyTorch3D row-vector convention);
+ *   - images are (B, V, 3, H, W) float32, contiguous — the layout
+ *     models/renderer.py:109-113 hands to its callers;
+ *   - return value: MVR_OK or an error code; mvr_last_error() gives the message.
+ */
+#ifndef MVR_H_
+#define MVR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mvr_stream_t;
+
+enum {
+  MVR_OK = 0,
+  MVR_ERR_INVALID_ARG = 1,
+  MVR_ERR_HIP = 2,
+  MVR_ERR_WORKSPACE = 3,
+  MVR_ERR_UNSUPPORTED = 4
+};
+
+/* flags for mvr_mesh_params.flags */
+enum {
+  MVR_CULL_BACKFACES = 1,      /* RasterizationSettings(cull_backfaces=...), models/renderer.py:98 */
+  MVR_PERSPECTIVE_CORRECT = 2  /* PyTorch3D >=0.5 default for perspective cameras */
+};
+
+/* A batch of B triangle meshes packed back to back (what models/renderer.py:66-77 builds
+ * as a PyTorch3D `Meshes`).  faces hold LOCAL vertex indices of their mesh. */
+typedef struct mvr_mesh_batch {
+  int32_t n_meshes;          /* B */
+  int32_t total_verts;       /* sum of Vn_b */
+  int32_t total_faces;       /* sum of F_b */
+  int32_t max_faces;         /* max F_b (host-known; sizes the launch) */
+  int32_t max_verts;         /* max Vn_b (host-known; sizes the launch) */
+  int32_t reserved_;         /* keeps the pointers 8-byte aligned; set to 0 */
+  const float *verts;        /* (total_verts, 3) world coordinates */
+  const int32_t *faces;      /* (total_faces, 3) */
+  const int32_t *vert_off;   /* (B+1) prefix sums of Vn_b */
+  const int32_t *face_off;   /* (B+1) prefix sums of F_b */
+  const float *vert_colors;  /* (total_verts, 3) or NULL: constant obj_color ("custom" colour, models/renderer.py:76-77,154-155) */
+} mvr_mesh_batch;
+
+/* Everything models/renderer.py:84-104 configures for the mesh path. */
+typedef struct mvr_mesh_params {
+  int32_t n_views;        /* V (views per mesh) */
+  int32_t image_h, image_w;
+  int32_t flags;          /* MVR_CULL_BACKFACES | MVR_PERSPECTIVE_CORRECT */
+  int32_t n_light;        /* rows of light_dir: 1 (shared) or N (per view) */
+  int32_t strip_rows;     /* rows per workgroup strip; 0 = library default */
+  float fov_deg;          /* FoVPerspectiveCameras default 60 */
+  float ambient, diffuse, specular, shininess; /* DirectionalLights/Materials defaults .5 .3 .2 64 */
+  float obj_color[3];     /* rendering_color(), models/renderer.py:153-160 */
+  float bg_color[3];      /* BlendParams(background_color), :102 */
+} mvr_mesh_params;
+
+typedef struct mvr_points_params {
+  int32_t n_clouds;       /* B */
+  int32_t n_points;       /* P per cloud */
+  int32_t n_views;        /* V */
+  int32_t image_h, image_w;
+  int32_t strip_rows;     /* 0 = default */
+  float radius;           /* PointsRasterizationSettings(radius), :131 */
+  float obj_color[3];
+  float bg_color[3];
+} mvr_points_params;
+
+int mvr_version(void);
+const char *mvr_last_error(void);
+
+/* ---- cameras ----------------------------------------------------------- */
+
+/* look_at_view_transform(dist, elev, azim) in degrees, at=origin, up=+Y
+ * (models/renderer.py:79-80,122-123) fused with the validity test of
+ * check_valid_rotation_matrix (util.py:403-420; ops.py:156-165 is the caller):
+ * view_valid[n] = 1 iff allclose(R R^T, I, atol=1e-6) and allclose(det R, 1);
+ * *n_invalid = number of invalid views (written, not accumulated).
+ * view_valid / n_invalid may be NULL. */
+int mvr_look_at(const float *azim, const float *elev, const float *dist, int32_t n,
+                float *R, float *T, int32_t *view_valid, int32_t *n_invalid,
+                mvr_stream_t stream);
+
+/* autograd backward of mvr_look_at: (dL/dR (n,9), dL/dT (n,3)) -> dL/d(azim, elev, dist) in
+ * the units of the inputs (degrees).  grad_R or grad_T may be NULL (treated as zero). */
+int mvr_look_at_backward(const float *azim, const float *elev, const float *dist, int32_t n,
+                         const float *grad_R, const float *grad_T, float *grad_azim,
+                         float *grad_elev, float *grad_dist, mvr_stream_t stream);
+
+/* camera_position_from_spherical_angles (models/renderer.py:168-169, "relative" light). */
+int mvr_camera_position(const float *azim, const float *elev, const float *dist, int32_t n,
+                        float *position, mvr_stream_t stream);
+int mvr_camera_position_backward(const float *azim, const float *elev, const float *dist,
+                                 int32_t n, const float *grad_position, float *grad_azim,
+                                 float *grad_elev, float *grad_dist, mvr_stream_t stream);
+
+/* ---- mesh path: models/renderer.py:65-114 ------------------------------ */
+
+/* Scratch the mesh calls need (vertex attributes, projected vertices, backward partials). */
+size_t mvr_mesh_workspace_bytes(const mvr_mesh_batch *meshes, const mvr_mesh_params *params);
+
+/* World-space area-weighted vertex normals (Meshes.verts_normals_packed, used by
+ * HardPhongShader at :102).  normals: (total_verts, 3).  Uses `workspace` as scratch. */
+int mvr_vertex_normals(const mvr_mesh_batch *meshes, float *normals, void *workspace,
+                       size_t workspace_bytes, mvr_stream_t stream);
+
+/* MeshRenderer(MeshRasterizer(blur_radius=0, faces_per_pixel=1), HardPhongShader) over the
+ * V-times extended batch (:89-107) + the re-layout of :109-113.
+ *   R (N,9), T (N,3): cameras;  light_dir (n_light,3): DirectionalLights direction (:190-191)
+ *   images (B,V,3,H,W) out;  pix_to_face (N,H,W) out or NULL: LOCAL face index, -1 = background
+ *   (must be non-NULL if mvr_render_meshes_backward will be called). */
+int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params,
+                              const float *R, const float *T, const float *light_dir,
+                              float *images, int32_t *pix_to_face, void *workspace,
+                              size_t workspace_bytes, mvr_stream_t stream);
+
+/* autograd backward of the above w.r.t. the cameras and the light (vertices carry no
+ * gradient in MVTN: they come from the DataLoader).  pix_to_face is treated as a constant,
+ * exactly as PyTorch3D's hard rasteriser/blend does (no coverage gradient).
+ *   grad_images (B,V,3,H,W) in;  grad_R (N,9), grad_T (N,3) out;
+ *   grad_light (N,3) out or NULL (only meaningful when n_light == N). */
+int mvr_render_meshes_backward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params,
+                               const float *R, const float *T, const float *light_dir,
+                               const int32_t *pix_to_face, const float *grad_images,
+                               float *grad_R, float *grad_T, float *grad_light,
+                               void *workspace, size_t workspace_bytes, mvr_stream_t stream);
+
+/* ---- point-cloud path: models/renderer.py:116-151 ---------------------- */
+
+size_t mvr_points_workspace_bytes(const mvr_points_params *params);
+
+/* Pointclouds.extend(V).scale_(1/dist) -> OpenGLOrthographicCameras(R,T) ->
+ * PointsRasterizer(radius, points_per_pixel=1) -> NormWeightedCompositor(background).
+ *   points (B,P,3); point_colors (B,P,3) or NULL (constant obj_color); dist (N);
+ *   images (B,V,3,H,W) out; pix_to_point (N,H,W) out or NULL (LOCAL point index, -1 empty). */
+int mvr_render_points_forward(const mvr_points_params *params, const float *points,
+                              const float *point_colors, const float *R, const float *T,
+                              const float *dist, float *images, int32_t *pix_to_point,
+                              void *workspace, size_t workspace_bytes, mvr_stream_t stream);
+
+/* backward w.r.t. cameras and dist.  With points_per_pixel = 1 the compositor's gradient
+ * vanishes except where the weight clamp max(w, 1e-4) is active. */
+int mvr_render_points_backward(const mvr_points_params *params, const float *points,
+                               const float *point_colors, const float *R, const float *T,
+                               const float *dist, const int32_t *pix_to_point,
+                               const float *grad_images, float *grad_R, float *grad_T,
+                               float *grad_dist, void *workspace, size_t workspace_bytes,
+                               mvr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVR_H_ */

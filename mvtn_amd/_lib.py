@@ -1,0 +1,84 @@
+"""ctypes binding of libmvr_hip.so (include/mvr.h).  There is NO fallback: if the HIP library
+is missing the import of any rendering entry point fails loudly."""
+import ctypes
+import os
+
+from . import build as _build
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+_vp = ctypes.c_void_p
+
+MVR_OK = 0
+MVR_CULL_BACKFACES = 1
+MVR_PERSPECTIVE_CORRECT = 2
+
+
+class MeshBatch(ctypes.Structure):  # struct mvr_mesh_batch
+    _fields_ = [("n_meshes", ctypes.c_int32), ("total_verts", ctypes.c_int32), ("total_faces", ctypes.c_int32),
+                ("max_faces", ctypes.c_int32), ("max_verts", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+                ("verts", _vp), ("faces", _vp), ("vert_off", _vp), ("face_off", _vp), ("vert_colors", _vp)]
+
+
+class MeshParams(ctypes.Structure):  # struct mvr_mesh_params
+    _fields_ = [("n_views", ctypes.c_int32), ("image_h", ctypes.c_int32), ("image_w", ctypes.c_int32),
+                ("flags", ctypes.c_int32), ("n_light", ctypes.c_int32), ("strip_rows", ctypes.c_int32),
+                ("fov_deg", ctypes.c_float), ("ambient", ctypes.c_float), ("diffuse", ctypes.c_float),
+                ("specular", ctypes.c_float), ("shininess", ctypes.c_float),
+                ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3)]
+
+
+class PointsParams(ctypes.Structure):  # struct mvr_points_params
+    _fields_ = [("n_clouds", ctypes.c_int32), ("n_points", ctypes.c_int32), ("n_views", ctypes.c_int32),
+                ("image_h", ctypes.c_int32), ("image_w", ctypes.c_int32), ("strip_rows", ctypes.c_int32),
+                ("radius", ctypes.c_float), ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3)]
+
+
+# name -> (restype, argtypes); mirrors include/mvr.h one to one
+_MB, _MP, _PP = ctypes.POINTER(MeshBatch), ctypes.POINTER(MeshParams), ctypes.POINTER(PointsParams)
+PROTOTYPES = {
+    "mvr_version": (ctypes.c_int, []),
+    "mvr_last_error": (ctypes.c_char_p, []),
+    "mvr_look_at": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "mvr_look_at_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvr_camera_position": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp]),
+    "mvr_camera_position_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "mvr_mesh_workspace_bytes": (ctypes.c_size_t, [_MB, _MP]),
+    "mvr_vertex_normals": (ctypes.c_int, [_MB, _vp, _vp, ctypes.c_size_t, _vp]),
+    "mvr_render_meshes_forward": (ctypes.c_int, [_MB, _MP, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "mvr_render_meshes_backward": (ctypes.c_int, [_MB, _MP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "mvr_points_workspace_bytes": (ctypes.c_size_t, [_PP]),
+    "mvr_render_points_forward": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "mvr_render_points_backward": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+}
+
+_LIB = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libmvr_hip.so (does not touch the GPU).  Raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "mvtn_amd: %s is missing — the HIP extension is the only rendering path (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `python -m mvtn_amd.build`." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != MVR_OK:
+        msg = load().mvr_last_error()
+        raise RuntimeError("mvr %s failed (code %d): %s" % (what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,441 @@
+// mvr_math.h — per-view / per-face / per-pixel arithmetic of the renderer, shared by every
+// kernel in mvr_kernels.hip.  Templated on the scalar so the same code is instantiated as
+// float on the device and (tests only, host build) as double for finite-difference checks.
+//
+// Everything that decides COVERAGE or DEPTH ORDER (view transform, projection, edge
+// functions, barycentrics, interpolated z) is written as explicit IEEE operations in a fixed
+// order and compiled with -ffp-contract=off: the pixel->face map must not depend on FMA
+// contraction.  The semantics are PyTorch3D 0.7.x as called from
+// models/renderer.py:65-151.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MVR_HD __host__ __device__ __forceinline__
+#else
+#include <cmath>
+#define MVR_HD inline
+#endif
+
+namespace mvr {
+
+constexpr float kEps = 1e-8f;          // PyTorch3D rasteriser kEpsilon
+constexpr float kNormalizeEps = 1e-6f; // F.normalize eps in shading / vertex normals
+constexpr float kLookAtEps = 1e-5f;    // F.normalize eps in look_at_rotation
+constexpr double kPi = 3.14159265358979323846;
+
+template <typename T> MVR_HD T tmin(T a, T b) { return a < b ? a : b; }
+template <typename T> MVR_HD T tmax(T a, T b) { return a > b ? a : b; }
+MVR_HD float tsqrt(float x) { return sqrtf(x); }
+MVR_HD double tsqrt(double x) { return sqrt(x); }
+MVR_HD float tabs(float x) { return fabsf(x); }
+MVR_HD double tabs(double x) { return fabs(x); }
+
+template <typename T> struct V3 { T x, y, z; };
+
+template <typename T> MVR_HD V3<T> cross(const V3<T> &a, const V3<T> &b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename T> MVR_HD T dot(const V3<T> &a, const V3<T> &b) {
+  return (a.x * b.x + a.y * b.y) + a.z * b.z;
+}
+
+// torch.nn.functional.normalize: v / max(||v||, eps); also returns the clamped norm.
+template <typename T> MVR_HD V3<T> normalize(const V3<T> &v, T eps, T *norm_out = nullptr, T *raw_norm = nullptr) {
+  T n = tsqrt((v.x * v.x + v.y * v.y) + v.z * v.z);
+  T d = tmax(n, eps);
+  if (norm_out) *norm_out = d;
+  if (raw_norm) *raw_norm = n;
+  return {v.x / d, v.y / d, v.z / d};
+}
+
+// gradient of normalize: out = v/d, d = max(n, eps).  n > eps: (g - out (out.g))/d ; else g/d.
+template <typename T> MVR_HD V3<T> normalize_bwd(const V3<T> &out, T d, bool clamped, const V3<T> &g) {
+  if (clamped) return {g.x / d, g.y / d, g.z / d};
+  T og = dot(out, g);
+  return {(g.x - out.x * og) / d, (g.y - out.y * og) / d, (g.z - out.z * og) / d};
+}
+
+// ---- cameras --------------------------------------------------------------------------
+
+// sin/cos of an angle in degrees: rad = float(pi/180) * deg in T, then correctly rounded
+// sin/cos (evaluate in double, round once).
+template <typename T> MVR_HD void sincos_deg(T deg, T *s, T *c) {
+  T rad = (T)(kPi / 180.0) * deg;
+  *s = (T)sin((double)rad);
+  *c = (T)cos((double)rad);
+}
+
+// camera_position_from_spherical_angles (models/renderer.py:168-169)
+template <typename T> MVR_HD V3<T> camera_position(T azim, T elev, T dist) {
+  T se, ce, sa, ca;
+  sincos_deg(elev, &se, &ce);
+  sincos_deg(azim, &sa, &ca);
+  return {(dist * ce) * sa, dist * se, (dist * ce) * ca};
+}
+
+// d(position)/d(azim, elev, dist) contracted with g (angles in degrees).
+template <typename T> MVR_HD void camera_position_bwd(T azim, T elev, T dist, const V3<T> &g, T *g_azim, T *g_elev, T *g_dist) {
+  T se, ce, sa, ca;
+  sincos_deg(elev, &se, &ce);
+  sincos_deg(azim, &sa, &ca);
+  const T k = (T)(kPi / 180.0);
+  *g_dist = (g.x * (ce * sa) + g.y * se) + g.z * (ce * ca);
+  *g_elev = k * (dist * ((g.x * (-se * sa) + g.y * ce) + g.z * (-se * ca)));
+  *g_azim = k * (dist * (g.x * (ce * ca) - g.z * (ce * sa)));
+}
+
+// look_at_view_transform (models/renderer.py:79-80): R row-major with axes as columns, T = -(R^T C).
+template <typename T> struct LookAtState {  // what the backward needs
+  V3<T> C, x, y, z, tx, ty;
+  T dz, dx, dy;           // clamped norms
+  bool cz, cx, cy;        // clamp active
+  bool repaired;
+};
+
+template <typename T> MVR_HD void look_at(T azim, T elev, T dist, T R[9], T Tr[3], LookAtState<T> *st = nullptr) {
+  V3<T> C = camera_position(azim, elev, dist);
+  V3<T> up = {(T)0, (T)1, (T)0};
+  V3<T> neg = {(T)0 - C.x, (T)0 - C.y, (T)0 - C.z};
+  T dz, nz, dx, nx, dy, ny;
+  V3<T> z = normalize(neg, (T)kLookAtEps, &dz, &nz);
+  V3<T> tx = cross(up, z);
+  V3<T> x = normalize(tx, (T)kLookAtEps, &dx, &nx);
+  V3<T> ty = cross(z, x);
+  V3<T> y = normalize(ty, (T)kLookAtEps, &dy, &ny);
+  bool repaired = false;
+  if (tabs(x.x) <= (T)5e-3 && tabs(x.y) <= (T)5e-3 && tabs(x.z) <= (T)5e-3) {
+    tx = cross(y, z);
+    x = normalize(tx, (T)kLookAtEps, &dx, &nx);
+    repaired = true;
+  }
+  R[0] = x.x; R[1] = y.x; R[2] = z.x;
+  R[3] = x.y; R[4] = y.y; R[5] = z.y;
+  R[6] = x.z; R[7] = y.z; R[8] = z.z;
+  Tr[0] = -((R[0] * C.x + R[3] * C.y) + R[6] * C.z);
+  Tr[1] = -((R[1] * C.x + R[4] * C.y) + R[7] * C.z);
+  Tr[2] = -((R[2] * C.x + R[5] * C.y) + R[8] * C.z);
+  if (st) {
+    st->C = C; st->x = x; st->y = y; st->z = z; st->tx = tx; st->ty = ty;
+    st->dz = dz; st->dx = dx; st->dy = dy;
+    st->cz = !(nz > (T)kLookAtEps); st->cx = !(nx > (T)kLookAtEps); st->cy = !(ny > (T)kLookAtEps);
+    st->repaired = repaired;
+  }
+}
+
+// check_valid_rotation_matrix (util.py:403-420) for one matrix.
+template <typename T> MVR_HD bool rotation_valid(const T M[9], T tol) {
+  bool ok = true;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      T v = (M[3 * r] * M[3 * c] + M[3 * r + 1] * M[3 * c + 1]) + M[3 * r + 2] * M[3 * c + 2];
+      T e = (r == c) ? (T)1 : (T)0;
+      T lim = tol + (T)1e-5 * e;
+      if (!(tabs(v - e) <= lim)) ok = false;
+    }
+  T det = (M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6])) +
+          M[2] * (M[3] * M[7] - M[4] * M[6]);
+  if (!(tabs(det - (T)1) <= (T)1e-8 + (T)1e-5)) ok = false;
+  return ok;
+}
+
+// backward of look_at: gR[9] (dL/dR row-major), gT[3] -> g_azim, g_elev, g_dist (degrees).
+template <typename T> MVR_HD void look_at_bwd(T azim, T elev, T dist, const T gR[9], const T gT[3], T *g_azim, T *g_elev, T *g_dist) {
+  T R[9], Tr[3];
+  LookAtState<T> st;
+  look_at(azim, elev, dist, R, Tr, &st);
+  V3<T> gx = {gR[0], gR[3], gR[6]}, gy = {gR[1], gR[4], gR[7]}, gz = {gR[2], gR[5], gR[8]};
+  // T_j = -(axis_j . C)
+  V3<T> gC = {-((gT[0] * st.x.x + gT[1] * st.y.x) + gT[2] * st.z.x),
+              -((gT[0] * st.x.y + gT[1] * st.y.y) + gT[2] * st.z.y),
+              -((gT[0] * st.x.z + gT[1] * st.y.z) + gT[2] * st.z.z)};
+  gx = {gx.x - gT[0] * st.C.x, gx.y - gT[0] * st.C.y, gx.z - gT[0] * st.C.z};
+  gy = {gy.x - gT[1] * st.C.x, gy.y - gT[1] * st.C.y, gy.z - gT[1] * st.C.z};
+  gz = {gz.x - gT[2] * st.C.x, gz.y - gT[2] * st.C.y, gz.z - gT[2] * st.C.z};
+  V3<T> up = {(T)0, (T)1, (T)0};
+  if (st.repaired) {
+    // x = normalize(cross(y, z)) replaced the first x (which still fed y)
+    V3<T> gtx = normalize_bwd(st.x, st.dx, st.cx, gx);
+    // c = y x z : g_y += z x gtx ; g_z += gtx x y
+    V3<T> a = cross(st.z, gtx), b = cross(gtx, st.y);
+    gy = {gy.x + a.x, gy.y + a.y, gy.z + a.z};
+    gz = {gz.x + b.x, gz.y + b.y, gz.z + b.z};
+    // recover the first x (what y was built from): x0 = normalize(up x z)
+    V3<T> tx0 = cross(up, st.z);
+    T d0, n0;
+    V3<T> x0 = normalize(tx0, (T)kLookAtEps, &d0, &n0);
+    V3<T> gty = normalize_bwd(st.y, st.dy, st.cy, gy);
+    V3<T> gz2 = cross(x0, gty), gx0 = cross(gty, st.z);
+    gz = {gz.x + gz2.x, gz.y + gz2.y, gz.z + gz2.z};
+    V3<T> gtx0 = normalize_bwd(x0, d0, !(n0 > (T)kLookAtEps), gx0);
+    V3<T> gz3 = cross(gtx0, up);
+    gz = {gz.x + gz3.x, gz.y + gz3.y, gz.z + gz3.z};
+  } else {
+    // y = normalize(z x x)
+    V3<T> gty = normalize_bwd(st.y, st.dy, st.cy, gy);
+    V3<T> gz2 = cross(st.x, gty), gx2 = cross(gty, st.z);
+    gz = {gz.x + gz2.x, gz.y + gz2.y, gz.z + gz2.z};
+    gx = {gx.x + gx2.x, gx.y + gx2.y, gx.z + gx2.z};
+    // x = normalize(up x z)
+    V3<T> gtx = normalize_bwd(st.x, st.dx, st.cx, gx);
+    V3<T> gz3 = cross(gtx, up);
+    gz = {gz.x + gz3.x, gz.y + gz3.y, gz.z + gz3.z};
+  }
+  // z = normalize(-C)
+  V3<T> gneg = normalize_bwd(st.z, st.dz, st.cz, gz);
+  gC = {gC.x - gneg.x, gC.y - gneg.y, gC.z - gneg.z};
+  camera_position_bwd(azim, elev, dist, gC, g_azim, g_elev, g_dist);
+}
+
+// Camera centre the shader uses: cameras.get_camera_center() = -T R^T.
+template <typename T> MVR_HD V3<T> camera_center(const T R[9], const T Tr[3]) {
+  return {-((Tr[0] * R[0] + Tr[1] * R[1]) + Tr[2] * R[2]),
+          -((Tr[0] * R[3] + Tr[1] * R[4]) + Tr[2] * R[5]),
+          -((Tr[0] * R[6] + Tr[1] * R[7]) + Tr[2] * R[8])};
+}
+
+// X_view = X_world R + T
+template <typename T> MVR_HD V3<T> world_to_view(const T R[9], const T Tr[3], const V3<T> &X) {
+  return {((X.x * R[0] + X.y * R[3]) + X.z * R[6]) + Tr[0],
+          ((X.x * R[1] + X.y * R[4]) + X.z * R[7]) + Tr[1],
+          ((X.x * R[2] + X.y * R[5]) + X.z * R[8]) + Tr[2]};
+}
+
+// FoVPerspectiveCameras (znear=1, aspect=1): s = 1/tan(fov/2)
+MVR_HD float fov_scale(float fov_deg) { return (float)(1.0 / tan(((double)fov_deg * (kPi / 180.0)) / 2.0)); }
+MVR_HD double fov_scale(double fov_deg) { return 1.0 / tan((fov_deg * (kPi / 180.0)) / 2.0); }
+
+// NDC x, y and VIEW z of a world vertex (MeshRasterizer.transform).
+template <typename T> MVR_HD V3<T> project_vertex(const T R[9], const T Tr[3], T s, const V3<T> &X) {
+  V3<T> v = world_to_view(R, Tr, X);
+  return {(s * v.x) / v.z, (s * v.y) / v.z, v.z};
+}
+
+// PixToNdc(i, S) = -1 + (2 i + 1)/S ; output column j <-> i = S-1-j (and rows likewise).
+template <typename T> MVR_HD T pix_to_ndc(int i, int S) { return (T)-1 + ((T)2 * (T)i + (T)1) / (T)S; }
+
+// ---- rasteriser: one (pixel, face) test ------------------------------------------------
+
+template <typename T> MVR_HD T edge_fn(T px, T py, T ax, T ay, T bx, T by) {
+  return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+template <typename T> struct FaceSetup {
+  V3<T> v0, v1, v2;            // NDC x, y ; view z
+  T xmin, xmax, ymin, ymax;
+  T area;                      // edge(v2; v0, v1) + kEps  (barycentric denominator)
+  bool drawable;               // passes the per-face culls
+};
+
+template <typename T> MVR_HD FaceSetup<T> face_setup(const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, bool cull_backfaces) {
+  FaceSetup<T> fs;
+  fs.v0 = v0; fs.v1 = v1; fs.v2 = v2;
+  fs.xmin = tmin(tmin(v0.x, v1.x), v2.x); fs.xmax = tmax(tmax(v0.x, v1.x), v2.x);
+  fs.ymin = tmin(tmin(v0.y, v1.y), v2.y); fs.ymax = tmax(tmax(v0.y, v1.y), v2.y);
+  T zmin = tmin(tmin(v0.z, v1.z), v2.z), zmax = tmax(tmax(v0.z, v1.z), v2.z);
+  T face_area = edge_fn(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+  bool back_face = face_area < (T)0;
+  bool zero_area = (face_area <= (T)kEps && face_area >= -(T)kEps);
+  bool z_invalid = zmin < (T)kEps;
+  fs.drawable = !(zmax < (T)0 || (cull_backfaces && back_face) || z_invalid || zero_area);
+  fs.area = edge_fn(v2.x, v2.y, v0.x, v0.y, v1.x, v1.y) + (T)kEps;
+  return fs;
+}
+
+// Barycentrics (optionally perspective-corrected) and interpolated z of pixel centre (px,py);
+// no inside test.
+template <typename T> MVR_HD void face_bary(const FaceSetup<T> &fs, T px, T py, bool persp, T *w0, T *w1, T *w2, T *pz) {
+  T a0 = edge_fn(px, py, fs.v1.x, fs.v1.y, fs.v2.x, fs.v2.y) / fs.area;
+  T a1 = edge_fn(px, py, fs.v2.x, fs.v2.y, fs.v0.x, fs.v0.y) / fs.area;
+  T a2 = edge_fn(px, py, fs.v0.x, fs.v0.y, fs.v1.x, fs.v1.y) / fs.area;
+  if (persp) {
+    T t0 = (a0 * fs.v1.z) * fs.v2.z, t1 = (fs.v0.z * a1) * fs.v2.z, t2 = (fs.v0.z * fs.v1.z) * a2;
+    T den = tmax((t0 + t1) + t2, (T)kEps);
+    a0 = t0 / den; a1 = t1 / den; a2 = t2 / den;
+  }
+  *w0 = a0; *w1 = a1; *w2 = a2;
+  *pz = (a0 * fs.v0.z + a1 * fs.v1.z) + a2 * fs.v2.z;
+}
+
+// CheckPixelInsideFace with blur_radius = 0: true iff the pixel centre is strictly inside.
+template <typename T> MVR_HD bool face_test(const FaceSetup<T> &fs, T px, T py, bool persp, T *pz, T *w0, T *w1, T *w2) {
+  if (px > fs.xmax || px < fs.xmin || py > fs.ymax || py < fs.ymin) return false;
+  // cheap sign pre-filter: e_i / area > 0 requires e_i != 0 with the sign of area
+  T e0 = edge_fn(px, py, fs.v1.x, fs.v1.y, fs.v2.x, fs.v2.y);
+  T e1 = edge_fn(px, py, fs.v2.x, fs.v2.y, fs.v0.x, fs.v0.y);
+  T e2 = edge_fn(px, py, fs.v0.x, fs.v0.y, fs.v1.x, fs.v1.y);
+  bool pos = fs.area > (T)0;
+  bool maybe = pos ? (e0 > (T)0 && e1 > (T)0 && e2 > (T)0) : (e0 < (T)0 && e1 < (T)0 && e2 < (T)0);
+  if (!maybe) return false;
+  face_bary(fs, px, py, persp, w0, w1, w2, pz);
+  if (*pz < (T)0) return false;
+  return *w0 > (T)0 && *w1 > (T)0 && *w2 > (T)0;
+}
+
+// ---- shading: HardPhongShader + DirectionalLights (models/renderer.py:102-103,190-191) ----
+
+template <typename T> struct Phong { T ambient, diffuse, specular, shininess; };
+
+template <typename T> MVR_HD T pow_shininess(T a, T shininess) {
+  if (shininess == (T)64) { T a2 = a * a, a4 = a2 * a2, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16; return a32 * a32; }
+  return (T)pow((double)a, (double)shininess);
+}
+
+// colour of one covered pixel.  X*, N*: world position / vertex normal of the face's
+// vertices; c*: their colours; l: light direction (towards the light); cc: camera centre.
+template <typename T> MVR_HD V3<T> phong_pixel(T w0, T w1, T w2, const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
+                                              const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
+                                              const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
+                                              const V3<T> &l, const V3<T> &cc, const Phong<T> &ph) {
+  V3<T> p = {(w0 * X0.x + w1 * X1.x) + w2 * X2.x, (w0 * X0.y + w1 * X1.y) + w2 * X2.y, (w0 * X0.z + w1 * X1.z) + w2 * X2.z};
+  V3<T> n = {(w0 * N0.x + w1 * N1.x) + w2 * N2.x, (w0 * N0.y + w1 * N1.y) + w2 * N2.y, (w0 * N0.z + w1 * N1.z) + w2 * N2.z};
+  V3<T> tex = {(w0 * c0.x + w1 * c1.x) + w2 * c2.x, (w0 * c0.y + w1 * c1.y) + w2 * c2.y, (w0 * c0.z + w1 * c1.z) + w2 * c2.z};
+  V3<T> nh = normalize(n, (T)kNormalizeEps);
+  V3<T> lh = normalize(l, (T)kNormalizeEps);
+  T cosang = dot(nh, lh);
+  T diff = cosang > (T)0 ? cosang : (T)0;
+  T mask = cosang > (T)0 ? (T)1 : (T)0;
+  V3<T> view = {cc.x - p.x, cc.y - p.y, cc.z - p.z};
+  V3<T> vh = normalize(view, (T)kNormalizeEps);
+  V3<T> refl = {-lh.x + (T)2 * (cosang * nh.x), -lh.y + (T)2 * (cosang * nh.y), -lh.z + (T)2 * (cosang * nh.z)};
+  T dvr = dot(vh, refl);
+  T alpha = (dvr > (T)0 ? dvr : (T)0) * mask;
+  T spec = ph.specular * pow_shininess(alpha, ph.shininess);
+  T sc = ph.ambient + ph.diffuse * diff;
+  return {sc * tex.x + spec, sc * tex.y + spec, sc * tex.z + spec};
+}
+
+// Per-pixel backward.  Inputs: the face's projected verts (fs), world attributes, upstream
+// gradient G (rgb).  Accumulates into acc[18]: gR[9], gT[3], gCc[3] (camera centre), gL[3].
+// pix_to_face is constant; relu / indicator kinks use subgradient 0.
+template <typename T> struct PixelGradIn {
+  T R[9], Tr[3], s;     // camera of the view, projection scale
+  V3<T> l, cc;          // light direction, camera centre
+  Phong<T> ph;
+  bool persp;
+};
+
+template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T px, T py,
+                                                  const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
+                                                  const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
+                                                  const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
+                                                  const V3<T> &G, T acc[18]) {
+  // ---- forward recompute -------------------------------------------------
+  V3<T> Xv0 = world_to_view(cam.R, cam.Tr, X0), Xv1 = world_to_view(cam.R, cam.Tr, X1), Xv2 = world_to_view(cam.R, cam.Tr, X2);
+  T u0 = (cam.s * Xv0.x) / Xv0.z, v0 = (cam.s * Xv0.y) / Xv0.z, z0 = Xv0.z;
+  T u1 = (cam.s * Xv1.x) / Xv1.z, v1 = (cam.s * Xv1.y) / Xv1.z, z1 = Xv1.z;
+  T u2 = (cam.s * Xv2.x) / Xv2.z, v2 = (cam.s * Xv2.y) / Xv2.z, z2 = Xv2.z;
+  T area = edge_fn(u2, v2, u0, v0, u1, v1) + (T)kEps;
+  T e0 = edge_fn(px, py, u1, v1, u2, v2), e1 = edge_fn(px, py, u2, v2, u0, v0), e2 = edge_fn(px, py, u0, v0, u1, v1);
+  T a0 = e0 / area, a1 = e1 / area, a2 = e2 / area;
+  T w0 = a0, w1 = a1, w2 = a2, den = (T)1;
+  bool den_clamped = false;
+  if (cam.persp) {
+    T t0 = (a0 * z1) * z2, t1 = (z0 * a1) * z2, t2 = (z0 * z1) * a2;
+    T sum = (t0 + t1) + t2;
+    den = tmax(sum, (T)kEps);
+    den_clamped = !(sum > (T)kEps);
+    w0 = t0 / den; w1 = t1 / den; w2 = t2 / den;
+  }
+  V3<T> p = {(w0 * X0.x + w1 * X1.x) + w2 * X2.x, (w0 * X0.y + w1 * X1.y) + w2 * X2.y, (w0 * X0.z + w1 * X1.z) + w2 * X2.z};
+  V3<T> n = {(w0 * N0.x + w1 * N1.x) + w2 * N2.x, (w0 * N0.y + w1 * N1.y) + w2 * N2.y, (w0 * N0.z + w1 * N1.z) + w2 * N2.z};
+  V3<T> tex = {(w0 * c0.x + w1 * c1.x) + w2 * c2.x, (w0 * c0.y + w1 * c1.y) + w2 * c2.y, (w0 * c0.z + w1 * c1.z) + w2 * c2.z};
+  T dn, rn, dl, rl, dv, rv;
+  V3<T> nh = normalize(n, (T)kNormalizeEps, &dn, &rn);
+  V3<T> lh = normalize(cam.l, (T)kNormalizeEps, &dl, &rl);
+  T cosang = dot(nh, lh);
+  bool lit = cosang > (T)0;
+  V3<T> view = {cam.cc.x - p.x, cam.cc.y - p.y, cam.cc.z - p.z};
+  V3<T> vh = normalize(view, (T)kNormalizeEps, &dv, &rv);
+  V3<T> refl = {-lh.x + (T)2 * (cosang * nh.x), -lh.y + (T)2 * (cosang * nh.y), -lh.z + (T)2 * (cosang * nh.z)};
+  T dvr = dot(vh, refl);
+  bool spec_on = lit && dvr > (T)0;
+  T alpha = spec_on ? dvr : (T)0;
+  T sc = cam.ph.ambient + cam.ph.diffuse * (lit ? cosang : (T)0);
+  // ---- backward ------------------------------------------------------------
+  V3<T> g_tex = {G.x * sc, G.y * sc, G.z * sc};
+  T g_sc = (G.x * tex.x + G.y * tex.y) + G.z * tex.z;
+  T g_cos = lit ? cam.ph.diffuse * g_sc : (T)0;
+  V3<T> g_nh = {(T)0, (T)0, (T)0}, g_lh = {(T)0, (T)0, (T)0}, g_p = {(T)0, (T)0, (T)0};
+  V3<T> g_cc = {(T)0, (T)0, (T)0};
+  if (spec_on) {
+    T g_spec = (G.x + G.y) + G.z;
+    // d(alpha^s)/d alpha = s * alpha^(s-1)
+    T dpow;
+    if (cam.ph.shininess == (T)64) {
+      T a2 = alpha * alpha, a4 = a2 * a2, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16;
+      dpow = (T)64 * (((a32 * a16) * (a8 * a4)) * (a2 * alpha));
+    } else {
+      dpow = cam.ph.shininess * (T)pow((double)alpha, (double)cam.ph.shininess - 1.0);
+    }
+    T g_dvr = cam.ph.specular * dpow * g_spec;
+    V3<T> g_vh = {g_dvr * refl.x, g_dvr * refl.y, g_dvr * refl.z};
+    V3<T> g_r = {g_dvr * vh.x, g_dvr * vh.y, g_dvr * vh.z};
+    g_lh = {-g_r.x, -g_r.y, -g_r.z};
+    g_cos += (T)2 * dot(g_r, nh);
+    g_nh = {(T)2 * cosang * g_r.x, (T)2 * cosang * g_r.y, (T)2 * cosang * g_r.z};
+    V3<T> g_view = normalize_bwd(vh, dv, !(rv > (T)kNormalizeEps), g_vh);
+    g_cc = g_view;
+    g_p = {-g_view.x, -g_view.y, -g_view.z};
+  }
+  g_nh = {g_nh.x + g_cos * lh.x, g_nh.y + g_cos * lh.y, g_nh.z + g_cos * lh.z};
+  g_lh = {g_lh.x + g_cos * nh.x, g_lh.y + g_cos * nh.y, g_lh.z + g_cos * nh.z};
+  V3<T> g_n = normalize_bwd(nh, dn, !(rn > (T)kNormalizeEps), g_nh);
+  V3<T> g_l = normalize_bwd(lh, dl, !(rl > (T)kNormalizeEps), g_lh);
+  // barycentric gradients
+  T gw0 = (dot(g_p, X0) + dot(g_n, N0)) + dot(g_tex, c0);
+  T gw1 = (dot(g_p, X1) + dot(g_n, N1)) + dot(g_tex, c1);
+  T gw2 = (dot(g_p, X2) + dot(g_n, N2)) + dot(g_tex, c2);
+  T ga0 = gw0, ga1 = gw1, ga2 = gw2, gz0 = (T)0, gz1 = (T)0, gz2 = (T)0;
+  if (cam.persp) {
+    T gt0, gt1, gt2;
+    if (den_clamped) {
+      gt0 = gw0 / den; gt1 = gw1 / den; gt2 = gw2 / den;
+    } else {
+      T s_ = (gw0 * w0 + gw1 * w1) + gw2 * w2;
+      gt0 = (gw0 - s_) / den; gt1 = (gw1 - s_) / den; gt2 = (gw2 - s_) / den;
+    }
+    ga0 = gt0 * (z1 * z2); gz1 += gt0 * (a0 * z2); gz2 += gt0 * (a0 * z1);
+    ga1 = gt1 * (z0 * z2); gz0 += gt1 * (a1 * z2); gz2 += gt1 * (z0 * a1);
+    ga2 = gt2 * (z0 * z1); gz0 += gt2 * (z1 * a2); gz1 += gt2 * (z0 * a2);
+  }
+  T ge0 = ga0 / area, ge1 = ga1 / area, ge2 = ga2 / area;
+  T g_area = -((ga0 * a0 + ga1 * a1) + ga2 * a2) / area;
+  // edge(p; a, b): d/dax = py - by ; d/day = bx - px ; d/dbx = ay - py ; d/dby = px - ax
+  T gu0 = (T)0, gv0 = (T)0, gu1 = (T)0, gv1 = (T)0, gu2 = (T)0, gv2 = (T)0;
+  // e0 = edge(p; V1, V2)
+  gu1 += ge0 * (py - v2); gv1 += ge0 * (u2 - px); gu2 += ge0 * (v1 - py); gv2 += ge0 * (px - u1);
+  // e1 = edge(p; V2, V0)
+  gu2 += ge1 * (py - v0); gv2 += ge1 * (u0 - px); gu0 += ge1 * (v2 - py); gv0 += ge1 * (px - u2);
+  // e2 = edge(p; V0, V1)
+  gu0 += ge2 * (py - v1); gv0 += ge2 * (u1 - px); gu1 += ge2 * (v0 - py); gv1 += ge2 * (px - u0);
+  // area = edge(V2; V0, V1): q = V2 -> d/dqx = (v1 - v0), d/dqy = -(u1 - u0); a = V0, b = V1 with p := V2
+  gu2 += g_area * (v1 - v0); gv2 += g_area * (-(u1 - u0));
+  gu0 += g_area * (v2 - v1); gv0 += g_area * (u1 - u2);
+  gu1 += g_area * (v0 - v2); gv1 += g_area * (u2 - u0);
+  // projection u = s x / z, v = s y / z, zv = z
+  auto proj_bwd = [&](const V3<T> &Xv, T u, T v, T gu, T gv, T gz, const V3<T> &Xw) {
+    T gx = gu * cam.s / Xv.z, gy = gv * cam.s / Xv.z;
+    T gzz = gz - (gu * u + gv * v) / Xv.z;
+    acc[0] += Xw.x * gx; acc[1] += Xw.x * gy; acc[2] += Xw.x * gzz;
+    acc[3] += Xw.y * gx; acc[4] += Xw.y * gy; acc[5] += Xw.y * gzz;
+    acc[6] += Xw.z * gx; acc[7] += Xw.z * gy; acc[8] += Xw.z * gzz;
+    acc[9] += gx; acc[10] += gy; acc[11] += gzz;
+  };
+  proj_bwd(Xv0, u0, v0, gu0, gv0, gz0, X0);
+  proj_bwd(Xv1, u1, v1, gu1, gv1, gz1, X1);
+  proj_bwd(Xv2, u2, v2, gu2, gv2, gz2, X2);
+  acc[12] += g_cc.x; acc[13] += g_cc.y; acc[14] += g_cc.z;
+  acc[15] += g_l.x; acc[16] += g_l.y; acc[17] += g_l.z;
+}
+
+// Fold the per-view camera-centre gradient into (gR, gT):  cc_i = -sum_j T_j R[i][j].
+template <typename T> MVR_HD void fold_camera_center(const T R[9], const T Tr[3], const T gcc[3], T gR[9], T gT[3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      gR[3 * i + j] += -gcc[i] * Tr[j];
+      gT[j] += -gcc[i] * R[3 * i + j];
+    }
+}
+
+}  // namespace mvr

@@ -1,0 +1,230 @@
+"""torch.autograd bindings of the C ABI (include/mvr.h).  PyTorch supplies device memory, the
+current HIP stream and autograd plumbing; all arithmetic happens in libmvr_hip.so."""
+import torch
+
+from . import _lib
+from .structures import PackedMeshes
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mvtn_amd: tensors must live on the GPU (the HIP library is the only path; there is no CPU fallback)")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------
+# cameras
+# ---------------------------------------------------------------------------------------------
+
+class _LookAt(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, azim, elev, dist):
+        lib = _lib.load()
+        azim, elev, dist = _f32c(azim), _f32c(elev), _f32c(dist)
+        _require_cuda(azim, elev, dist)
+        n = azim.numel()
+        R = torch.empty(n, 3, 3, dtype=torch.float32, device=azim.device)
+        T = torch.empty(n, 3, dtype=torch.float32, device=azim.device)
+        status = torch.empty(n + 1, dtype=torch.int32, device=azim.device)  # [0] = #invalid, [1:] per-view valid
+        _lib.check(lib.mvr_look_at(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), n, R.data_ptr(), T.data_ptr(),
+                                   status[1:].data_ptr(), status.data_ptr(), _stream()), "mvr_look_at")
+        ctx.save_for_backward(azim, elev, dist)
+        ctx.mark_non_differentiable(status)
+        return R, T, status
+
+    @staticmethod
+    def backward(ctx, gR, gT, _gs):
+        lib = _lib.load()
+        azim, elev, dist = ctx.saved_tensors
+        n = azim.numel()
+        gR = None if gR is None else _f32c(gR)
+        gT = None if gT is None else _f32c(gT)
+        ga, ge, gd = torch.empty_like(azim), torch.empty_like(elev), torch.empty_like(dist)
+        _lib.check(lib.mvr_look_at_backward(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), n, _ptr(gR), _ptr(gT),
+                                            ga.data_ptr(), ge.data_ptr(), gd.data_ptr(), _stream()), "mvr_look_at_backward")
+        return ga, ge, gd
+
+
+def look_at_view_transform(dist, elev, azim, return_status=False):
+    """R (N,3,3), T (N,3) for flat per-view (N,) distance / elevation / azimuth in degrees —
+    pytorch3d look_at_view_transform as called at models/renderer.py:79-80 — differentiable.
+    status[0] = number of views failing check_valid_rotation_matrix (util.py:403-420),
+    status[1:] = per-view validity; both computed on the device without a host sync."""
+    shape = azim.shape
+    R, T, status = _LookAt.apply(azim.reshape(-1), elev.reshape(-1), dist.reshape(-1))
+    assert len(shape) == 1
+    return (R, T, status) if return_status else (R, T)
+
+
+class _CameraPosition(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, azim, elev, dist):
+        lib = _lib.load()
+        azim, elev, dist = _f32c(azim), _f32c(elev), _f32c(dist)
+        _require_cuda(azim, elev, dist)
+        n = azim.numel()
+        C = torch.empty(n, 3, dtype=torch.float32, device=azim.device)
+        _lib.check(lib.mvr_camera_position(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), n, C.data_ptr(), _stream()),
+                   "mvr_camera_position")
+        ctx.save_for_backward(azim, elev, dist)
+        return C
+
+    @staticmethod
+    def backward(ctx, gC):
+        lib = _lib.load()
+        azim, elev, dist = ctx.saved_tensors
+        gC = _f32c(gC)
+        ga, ge, gd = torch.empty_like(azim), torch.empty_like(elev), torch.empty_like(dist)
+        _lib.check(lib.mvr_camera_position_backward(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), azim.numel(),
+                                                    gC.data_ptr(), ga.data_ptr(), ge.data_ptr(), gd.data_ptr(), _stream()),
+                   "mvr_camera_position_backward")
+        return ga, ge, gd
+
+
+def camera_position_from_spherical_angles(distance, elevation, azimuth):
+    """(N,3) camera positions (degrees) — models/renderer.py:168-169 — differentiable."""
+    return _CameraPosition.apply(azimuth.reshape(-1), elevation.reshape(-1), distance.reshape(-1))
+
+
+# ---------------------------------------------------------------------------------------------
+# mesh path
+# ---------------------------------------------------------------------------------------------
+
+def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backfaces=False, perspective_correct=True,
+                fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, strip_rows=0):
+    H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
+    flags = (_lib.MVR_CULL_BACKFACES if cull_backfaces else 0) | (_lib.MVR_PERSPECTIVE_CORRECT if perspective_correct else 0)
+    p = _lib.MeshParams(n_views, H, W, flags, n_light, strip_rows, fov, ambient, diffuse, specular, shininess)
+    for k in range(3):
+        p.obj_color[k] = float(obj_color[k])
+        p.bg_color[k] = float(bg_color[k])
+    return p
+
+
+class _RenderMeshes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R, T, light, packed, params, need_grad):
+        lib = _lib.load()
+        R, T, light = _f32c(R), _f32c(T), _f32c(light)
+        _require_cuda(R, T, light, packed.verts)
+        B, V, H, W = packed.n_meshes, params.n_views, params.image_h, params.image_w
+        N = B * V
+        if R.shape[0] != N or T.shape[0] != N:
+            raise ValueError("R/T must have B*V = %d rows" % N)
+        dev = R.device
+        mb = packed.c_struct()
+        ws_bytes = lib.mvr_mesh_workspace_bytes(mb, params)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=dev)
+        p2f = torch.empty(N, H, W, dtype=torch.int32, device=dev) if need_grad else None
+        _lib.check(lib.mvr_render_meshes_forward(mb, params, R.data_ptr(), T.data_ptr(), light.data_ptr(), images.data_ptr(),
+                                                 _ptr(p2f), ws.data_ptr(), ws_bytes, _stream()), "mvr_render_meshes_forward")
+        if need_grad:
+            ctx.save_for_backward(R, T, light, p2f)
+            ctx.packed, ctx.params = packed, params
+        return images
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        R, T, light, p2f = ctx.saved_tensors
+        packed, params = ctx.packed, ctx.params
+        g = _f32c(g)
+        N = R.shape[0]
+        mb = packed.c_struct()
+        ws_bytes = lib.mvr_mesh_workspace_bytes(mb, params)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=R.device)
+        gR, gT = torch.empty_like(R), torch.empty_like(T)
+        per_view_light = params.n_light == N and N > 0 and ctx.needs_input_grad[2]
+        gL = torch.empty(N, 3, dtype=torch.float32, device=R.device) if per_view_light else None
+        _lib.check(lib.mvr_render_meshes_backward(mb, params, R.data_ptr(), T.data_ptr(), light.data_ptr(), p2f.data_ptr(),
+                                                  g.data_ptr(), gR.data_ptr(), gT.data_ptr(), _ptr(gL), ws.data_ptr(), ws_bytes,
+                                                  _stream()), "mvr_render_meshes_backward")
+        return gR, gT, gL, None, None, None
+
+
+def render_meshes(packed: PackedMeshes, R, T, light_dir, params):
+    """images (B,V,3,H,W) — MeshRenderer(MeshRasterizer, HardPhongShader) of models/renderer.py:89-107
+    plus the re-layout of :109-113; differentiable w.r.t. R, T and a per-view light_dir."""
+    need_grad = torch.is_grad_enabled() and (R.requires_grad or T.requires_grad or light_dir.requires_grad)
+    return _RenderMeshes.apply(R, T, light_dir, packed, params, need_grad)
+
+
+def vertex_normals(packed: PackedMeshes):
+    lib = _lib.load()
+    mb = packed.c_struct()
+    p = mesh_params(1, 8, 1, (1, 1, 1), (1, 1, 1))
+    ws_bytes = lib.mvr_mesh_workspace_bytes(mb, p)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=packed.device)
+    out = torch.empty(packed.total_verts, 3, dtype=torch.float32, device=packed.device)
+    _lib.check(lib.mvr_vertex_normals(mb, out.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "mvr_vertex_normals")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# point-cloud path
+# ---------------------------------------------------------------------------------------------
+
+def points_params(n_clouds, n_points, n_views, image_size, radius, obj_color, bg_color, strip_rows=0):
+    H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
+    p = _lib.PointsParams(n_clouds, n_points, n_views, H, W, strip_rows, radius)
+    for k in range(3):
+        p.obj_color[k] = float(obj_color[k])
+        p.bg_color[k] = float(bg_color[k])
+    return p
+
+
+class _RenderPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R, T, dist, points, colors, params, need_grad):
+        lib = _lib.load()
+        R, T, dist = _f32c(R), _f32c(T), _f32c(dist)
+        _require_cuda(R, T, dist, points, colors)
+        B, V, H, W = params.n_clouds, params.n_views, params.image_h, params.image_w
+        N = B * V
+        if R.shape[0] != N or dist.numel() != N:
+            raise ValueError("R/T/dist must have B*V = %d rows" % N)
+        images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=R.device)
+        p2p = torch.empty(N, H, W, dtype=torch.int32, device=R.device) if need_grad else None
+        _lib.check(lib.mvr_render_points_forward(params, points.data_ptr(), _ptr(colors), R.data_ptr(), T.data_ptr(),
+                                                 dist.data_ptr(), images.data_ptr(), _ptr(p2p), None, 0, _stream()),
+                   "mvr_render_points_forward")
+        if need_grad:
+            ctx.save_for_backward(R, T, dist, points, p2p)
+            ctx.colors, ctx.params = colors, params
+        return images
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        R, T, dist, points, p2p = ctx.saved_tensors
+        params, colors = ctx.params, ctx.colors
+        g = _f32c(g)
+        ws_bytes = lib.mvr_points_workspace_bytes(params)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=R.device)
+        gR, gT, gD = torch.empty_like(R), torch.empty_like(T), torch.empty_like(dist)
+        _lib.check(lib.mvr_render_points_backward(params, points.data_ptr(), _ptr(colors), R.data_ptr(), T.data_ptr(),
+                                                  dist.data_ptr(), p2p.data_ptr(), g.data_ptr(), gR.data_ptr(), gT.data_ptr(),
+                                                  gD.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "mvr_render_points_backward")
+        return gR, gT, gD, None, None, None, None
+
+
+def render_points(points, colors, R, T, dist, params):
+    """images (B,V,3,H,W) — PointsRenderer(PointsRasterizer, NormWeightedCompositor) over the
+    1/dist-scaled clouds of models/renderer.py:129-145 plus the re-layout of :146-150."""
+    need_grad = torch.is_grad_enabled() and (R.requires_grad or T.requires_grad or dist.requires_grad)
+    return _RenderPoints.apply(R, T, dist, points, colors, params, need_grad)

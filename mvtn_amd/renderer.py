@@ -1,0 +1,162 @@
+"""MVRenderer — drop-in for the reference's models/renderer.py::MVRenderer (lines 33-207):
+same constructor, same forward(meshes, points, azim, elev, dist, color=None) ->
+(rendered_images (B,V,3,H,W), cameras), same .train()/.eval() behaviour switches; the
+PyTorch3D calls are replaced by hand-written gfx950 HIP kernels behind include/mvr.h.
+
+Extra keyword-only constructor arguments (defaults reproduce the reference + PyTorch3D 0.7.x):
+  perspective_correct  PyTorch3D's RasterizationSettings.perspective_correct (None->True for
+                       perspective cameras since 0.5; 0.4 used False)        [SURVEY App. A.9(i)]
+  rotation_check       "sync": reference behaviour — after enqueueing the render, read the device-side
+                       validity count (one host sync, as check_valid_rotation_matrix costs the
+                       reference, util.py:417-420) and run the random-perturbation remedy of
+                       ops.py:156-165 if any R is invalid;  "off": skip the read (no host sync).
+"""
+import sys
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import functional as F
+from .helpers import flatten_views, torch_color
+from .structures import Cameras, PackedMeshes
+
+ORTHOGONAL_THRESHOLD = 1e-6
+EXAHSTION_LIMIT = 20  # models/renderer.py:30 (the reference's spelling)
+
+
+class MVRenderer(nn.Module):
+    def __init__(self, nb_views, image_size=224, pc_rendering=True, object_color="white", background_color="white",
+                 faces_per_pixel=1, points_radius=0.006, points_per_pixel=1, light_direction="random",
+                 cull_backfaces=False, *, perspective_correct=True, rotation_check="sync", strip_rows=0):
+        super().__init__()
+        self.nb_views = nb_views
+        self.image_size = image_size
+        self.pc_rendering = pc_rendering
+        self.object_color = object_color
+        self.background_color = background_color
+        self.faces_per_pixel = faces_per_pixel
+        self.points_radius = points_radius
+        self.points_per_pixel = points_per_pixel
+        self.light_direction_type = light_direction
+        self.cull_backfaces = cull_backfaces
+        self.perspective_correct = perspective_correct
+        if rotation_check not in ("sync", "off"):
+            raise ValueError("rotation_check must be 'sync' or 'off'")
+        self.rotation_check = rotation_check
+        self.strip_rows = strip_rows
+        # faces_per_pixel > 1 does not change a HardPhongShader image (hard_rgb_blend reads only
+        # the nearest face), so any value >= 1 renders identically; points_per_pixel > 1 would.
+        if int(points_per_pixel) != 1:
+            raise NotImplementedError("points_per_pixel != 1 is not implemented (reference default is 1, config.yaml:21)")
+
+    # -- models/renderer.py:153-160 -----------------------------------------------------------
+    def rendering_color(self, custom_color=(1.0, 0, 0)):
+        if self.object_color == "custom":
+            color = custom_color
+        elif self.object_color == "random" and not self.training:
+            color = torch_color("white")
+        else:
+            color = torch_color(self.object_color, max_lightness=True)
+        return color
+
+    # -- models/renderer.py:162-171 -----------------------------------------------------------
+    def light_direction(self, azim, elev, dist):
+        if self.light_direction_type == "fixed":
+            return ((0, 1.0, 0),)
+        elif self.light_direction_type == "random" and self.training:
+            return (tuple(1.0 - 2 * np.random.rand(3)),)
+        else:  # "relative", or "random" in eval: the camera position of every view (keeps autograd)
+            return F.camera_position_from_spherical_angles(flatten_views(dist), flatten_views(elev), flatten_views(azim))
+
+    # -- look_at + ops.py:156-165 check_and_correct_rotation_matrix ----------------------------
+    def _cameras(self, azim, elev, dist):
+        return F.look_at_view_transform(flatten_views(dist), flatten_views(elev), flatten_views(azim), return_status=True)
+
+    def _remedy(self, azim, elev, dist):
+        """Random re-draw of ALL views until every R is valid (ops.py:156-165)."""
+        exhastion = 0
+        while True:
+            exhastion += 1
+            R, T, status = self._cameras(azim + 180.0 * torch.rand_like(azim), elev + 90.0 * torch.rand_like(elev), dist)
+            bad = int(status[0].item())
+            if bad == 0:
+                return R, T
+            if exhastion > EXAHSTION_LIMIT:
+                sys.exit("Remedy did not work")
+
+    # -- models/renderer.py:65-114 ---------------------------------------------------------------
+    def render_meshes(self, meshes, color, azim, elev, dist, lights, background_color=(1.0, 1.0, 1.0)):
+        device = azim.device
+        vert_colors = None
+        if torch.is_tensor(color) and color.dim() >= 2:  # "custom": per-vertex colours (B, >=Vn, 3)
+            vert_colors, obj = color, (1.0, 1.0, 1.0)
+        else:
+            obj = [float(c) for c in color]
+        if isinstance(meshes, PackedMeshes):
+            packed = meshes
+        else:
+            packed = PackedMeshes.from_meshes(meshes, device, vert_colors)
+        N = packed.n_meshes * self.nb_views
+        if torch.is_tensor(lights):
+            light = lights
+        else:
+            light = torch.tensor(lights, dtype=torch.float32).reshape(-1, 3).to(device, non_blocking=True)
+        params = F.mesh_params(self.nb_views, self.image_size, light.shape[0], obj, [float(c) for c in background_color],
+                               cull_backfaces=bool(self.cull_backfaces), perspective_correct=bool(self.perspective_correct),
+                               strip_rows=self.strip_rows)
+        if azim.numel() != N:
+            raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (packed.n_meshes, self.nb_views))
+        R, T, status = self._cameras(azim, elev, dist)
+        images = F.render_meshes(packed, R, T, light, params)
+        if self.rotation_check == "sync" and int(status[0].item()) != 0:
+            R, T = self._remedy(azim, elev, dist)
+            images = F.render_meshes(packed, R, T, light, params)
+        return images, Cameras(R, T, "perspective")
+
+    # -- models/renderer.py:116-151 ----------------------------------------------------------------
+    def render_points(self, points, color, azim, elev, dist, background_color=(0.0, 0.0, 0.0)):
+        device = azim.device
+        B, P = points.shape[0], points.shape[1]
+        pts = points.to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
+        colors = None
+        if torch.is_tensor(color) and color.dim() >= 2:  # per-point colours (B, P, 3)
+            colors, obj = color.to(device=device, dtype=torch.float32).expand(B, P, 3).contiguous(), (1.0, 1.0, 1.0)
+        else:
+            obj = [float(c) for c in color]
+        params = F.points_params(B, P, self.nb_views, self.image_size, float(self.points_radius), obj,
+                                 [float(c) for c in background_color], strip_rows=self.strip_rows)
+        if azim.numel() != B * self.nb_views:
+            raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (B, self.nb_views))
+        flat_dist = flatten_views(dist)
+        R, T, status = self._cameras(azim, elev, dist)
+        images = F.render_points(pts, colors, R, T, flat_dist, params)
+        if self.rotation_check == "sync" and int(status[0].item()) != 0:
+            R, T = self._remedy(azim, elev, dist)
+            images = F.render_points(pts, colors, R, T, flat_dist, params)
+        return images, Cameras(R, T, "orthographic", znear=0.01)
+
+    # -- models/renderer.py:173-198 ------------------------------------------------------------------
+    def forward(self, meshes, points, azim, elev, dist, color=None):
+        """meshes: list of B single-mesh objects with verts_list()/faces_list() (or one batched
+        object, or a PackedMeshes already resident on the GPU), or None; points: (B,P,3) or None;
+        azim/elev/dist: (B, nb_views) float tensors on the GPU, degrees.
+        Returns (rendered_images (B, nb_views, 3, H, W) float32, cameras)."""
+        if not azim.is_cuda:
+            raise RuntimeError("MVRenderer: azim/elev/dist must be CUDA tensors (models/renderer.py hard-codes .cuda() too)")
+        background_color = torch_color(self.background_color, max_lightness=True)
+        color = self.rendering_color(color)
+        if not self.pc_rendering:
+            lights = self.light_direction(azim, elev, dist)
+            return self.render_meshes(meshes=meshes, color=color, azim=azim, elev=elev, dist=dist, lights=lights,
+                                      background_color=background_color)
+        return self.render_points(points=points, color=color, azim=azim, elev=elev, dist=dist,
+                                  background_color=background_color)
+
+    # -- models/renderer.py:200-207 -------------------------------------------------------------------
+    def render_and_save(self, meshes, points, azim, elev, dist, images_path, cameras_path, color=None):
+        from .viz import save_cameras, save_grid
+        with torch.no_grad():
+            rendered_images, cameras = self.forward(meshes, points, azim, elev, dist, color)
+        save_grid(image_batch=rendered_images[0, ...], save_path=images_path, nrow=self.nb_views)
+        save_cameras(cameras, save_path=cameras_path, scale=0.22, dpi=200)

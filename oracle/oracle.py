@@ -1,0 +1,179 @@
+"""oracle/oracle.py — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+numpy/ctypes front-end of the CPU oracle (``liboracle.so``, built from
+``mvr_oracle.c`` by ``oracle/Makefile``).  It restates, on the CPU, the
+PyTorch3D arithmetic that the reference's ``models/renderer.py:65-198`` calls
+(look-at, projection, naive z-buffered rasterisation, Phong + hard blend, point
+splat + norm-weighted compositing).  PyTorch3D is not vendored by the reference
+and not installable here, so this oracle is **parity unpinned** (SURVEY.md
+section 8c): it is checked against analytic known-answer tests and the golden
+caller-side fixtures only.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module.  The product (``mvtn_amd``) never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (seconds)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("mvr_oracle.c", "mvr_oracle_impl.inc", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+    return _LIB
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _sfx(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "_f32", ctypes.c_float
+    if dtype == np.float64:
+        return "_f64", ctypes.c_double
+    raise TypeError(dtype)
+
+
+def _flat(x, dtype):
+    return np.ascontiguousarray(np.asarray(x, dtype=dtype).reshape(-1))
+
+
+def camera_position(azim, elev, dist, dtype=np.float32):
+    sfx, _ = _sfx(dtype)
+    a, e, d = _flat(azim, dtype), _flat(elev, dtype), _flat(dist, dtype)
+    n = a.size
+    C = np.empty((n, 3), dtype)
+    getattr(lib(), "orc_camera_position" + sfx)(ctypes.c_int(n), _ptr(a), _ptr(e), _ptr(d), _ptr(C))
+    return C
+
+
+def look_at(azim, elev, dist, dtype=np.float32):
+    """R (n,3,3), T (n,3) of look_at_view_transform(dist, elev, azim) in degrees."""
+    sfx, _ = _sfx(dtype)
+    a, e, d = _flat(azim, dtype), _flat(elev, dtype), _flat(dist, dtype)
+    n = a.size
+    R = np.empty((n, 3, 3), dtype)
+    T = np.empty((n, 3), dtype)
+    getattr(lib(), "orc_look_at" + sfx)(ctypes.c_int(n), _ptr(a), _ptr(e), _ptr(d), _ptr(R), _ptr(T))
+    return R, T
+
+
+def check_rotation(R, tol=1e-6):
+    """(all_valid, per-view flags) of util.py:403-420 check_valid_rotation_matrix."""
+    R = np.ascontiguousarray(R)
+    sfx, cty = _sfx(R.dtype)
+    n = R.shape[0]
+    flags = np.empty(n, np.int32)
+    fn = getattr(lib(), "orc_check_rotation" + sfx)
+    fn.restype = ctypes.c_int
+    ok = fn(ctypes.c_int(n), _ptr(R), cty(tol), _ptr(flags))
+    return bool(ok), flags.astype(bool)
+
+
+def vertex_normals(verts, faces):
+    verts = np.ascontiguousarray(verts)
+    sfx, _ = _sfx(verts.dtype)
+    faces = np.ascontiguousarray(faces, dtype=np.int64)
+    out = np.empty_like(verts)
+    getattr(lib(), "orc_vertex_normals" + sfx)(
+        ctypes.c_int(verts.shape[0]), ctypes.c_int(faces.shape[0]), _ptr(verts), _ptr(faces), _ptr(out))
+    return out
+
+
+def pack_meshes(verts_list, faces_list, dtype=np.float32):
+    vert_off = np.zeros(len(verts_list) + 1, np.int32)
+    face_off = np.zeros(len(verts_list) + 1, np.int32)
+    for i, (v, f) in enumerate(zip(verts_list, faces_list)):
+        vert_off[i + 1] = vert_off[i] + len(v)
+        face_off[i + 1] = face_off[i] + len(f)
+    verts = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype).reshape(-1, 3) for v in verts_list], 0))
+    faces = np.ascontiguousarray(np.concatenate([np.asarray(f, np.int64).reshape(-1, 3) for f in faces_list], 0))
+    return verts, faces, vert_off, face_off
+
+
+def render_meshes(verts_list, faces_list, azim, elev, dist, image_size, light_dir=((0.0, 1.0, 0.0),),
+                  obj_color=(1.0, 1.0, 1.0), bg_color=(1.0, 1.0, 1.0), vert_colors=None,
+                  perspective_correct=True, cull_backfaces=False, fov=60.0,
+                  ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0,
+                  mode=1, fixed_p2f=None, dtype=np.float32, R=None, T=None, return_fragments=True):
+    """Restates models/renderer.py:65-114.  azim/elev/dist: (B,V) degrees.
+    Returns dict(images (B,V,3,H,W), pix_to_face (N,H,W) local idx, zbuf, bary (N,H,W,3), R, T)."""
+    sfx, cty = _sfx(dtype)
+    azim = np.asarray(azim, dtype)
+    B, V = azim.shape
+    N = B * V
+    H = W = int(image_size)
+    verts, faces, vert_off, face_off = pack_meshes(verts_list, faces_list, dtype)
+    if R is None:
+        R, T = look_at(azim, elev, dist, dtype)
+    R = np.ascontiguousarray(R, dtype)
+    T = np.ascontiguousarray(T, dtype)
+    light = np.ascontiguousarray(np.asarray(light_dir, dtype).reshape(-1, 3))
+    assert light.shape[0] in (1, N)
+    vc = None if vert_colors is None else np.ascontiguousarray(np.asarray(vert_colors, dtype).reshape(-1, 3))
+    oc = _flat(obj_color, dtype)
+    bg = _flat(bg_color, dtype)
+    images = np.empty((B, V, 3, H, W), dtype)
+    p2f = np.empty((N, H, W), np.int32) if return_fragments else None
+    zbuf = np.empty((N, H, W), dtype) if return_fragments else None
+    bary = np.empty((N, H, W, 3), dtype) if return_fragments else None
+    fixed = None if fixed_p2f is None else np.ascontiguousarray(fixed_p2f, np.int32)
+    getattr(lib(), "orc_render_meshes" + sfx)(
+        ctypes.c_int(B), ctypes.c_int(V), ctypes.c_int(H), ctypes.c_int(W),
+        _ptr(verts), _ptr(faces), _ptr(vert_off), _ptr(face_off), _ptr(R), _ptr(T),
+        _ptr(light), ctypes.c_int(light.shape[0]), _ptr(vc), _ptr(oc), _ptr(bg),
+        ctypes.c_int(int(perspective_correct)), ctypes.c_int(int(cull_backfaces)),
+        cty(fov), cty(ambient), cty(diffuse), cty(specular), cty(shininess),
+        ctypes.c_int(mode), _ptr(fixed), _ptr(images), _ptr(p2f), _ptr(zbuf), _ptr(bary))
+    return dict(images=images, pix_to_face=p2f, zbuf=zbuf, bary=bary, R=R, T=T)
+
+
+def render_points(points, azim, elev, dist, image_size, radius=0.006, obj_color=(1.0, 1.0, 1.0),
+                  bg_color=(1.0, 1.0, 1.0), point_colors=None, mode=1, fixed_idx=None,
+                  dtype=np.float32, R=None, T=None, return_fragments=True):
+    """Restates models/renderer.py:116-151.  points (B,P,3); azim/elev/dist (B,V)."""
+    sfx, cty = _sfx(dtype)
+    azim = np.asarray(azim, dtype)
+    B, V = azim.shape
+    N = B * V
+    H = W = int(image_size)
+    pts = np.ascontiguousarray(np.asarray(points, dtype))
+    assert pts.shape[0] == B and pts.shape[2] == 3
+    P = pts.shape[1]
+    if R is None:
+        R, T = look_at(azim, elev, dist, dtype)
+    R = np.ascontiguousarray(R, dtype)
+    T = np.ascontiguousarray(T, dtype)
+    d = _flat(dist, dtype)
+    assert d.size == N
+    pc = None if point_colors is None else np.ascontiguousarray(np.asarray(point_colors, dtype))
+    oc = _flat(obj_color, dtype)
+    bg = _flat(bg_color, dtype)
+    images = np.empty((B, V, 3, H, W), dtype)
+    idx = np.empty((N, H, W), np.int32) if return_fragments else None
+    zbuf = np.empty((N, H, W), dtype) if return_fragments else None
+    d2 = np.empty((N, H, W), dtype) if return_fragments else None
+    fixed = None if fixed_idx is None else np.ascontiguousarray(fixed_idx, np.int32)
+    getattr(lib(), "orc_render_points" + sfx)(
+        ctypes.c_int(B), ctypes.c_int(V), ctypes.c_int(P), ctypes.c_int(H), ctypes.c_int(W),
+        _ptr(pts), _ptr(R), _ptr(T), _ptr(d), _ptr(pc), _ptr(oc), _ptr(bg),
+        ctypes.c_double(radius), ctypes.c_int(mode), _ptr(fixed),
+        _ptr(images), _ptr(idx), _ptr(zbuf), _ptr(d2))
+    return dict(images=images, idx=idx, zbuf=zbuf, dist2=d2, R=R, T=T)
