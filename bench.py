@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py — rendered views/s of the MVRenderer hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mesh_fwd|mesh_fwdbwd|points_fwd]
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
+MVRenderer.forward (look-at + validity/remedy + vertex normals + projection + rasterise + shade) on
+B=16 "ModelNet-simplified-sized" meshes x 12 spherical views at 224x224 (BASELINE.json configs[1]).
+For N>1 the driver launches one rank per GPU with torch.distributed.run; every rank renders its own
+B objects (the (B x V) view axis shards by object: weak scaling, no data-path collective); the
+RCCL all-gather of the rendered views the north_star names is timed separately and reported beside it.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      algorithmic HBM bytes per launch of the dominant kernel / its HIP-event duration
+  cpu_baseline  the CPU oracle's literal pixel-major loop ("restated PyTorch3D-semantics CPU
+                reference", 1 thread) on a bounded sample of the same workload
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="mesh_fwd", choices=["mesh_fwd", "mesh_fwdbwd", "points_fwd"])
+    ap.add_argument("--batch", type=int, default=0, help="objects per GPU (default: the BASELINE config's)")
+    ap.add_argument("--views", type=int, default=0)
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--tier", default="M")
+    ap.add_argument("--strip-rows", type=int, default=0)
+    ap.add_argument("--rotation-check", default="device", choices=["device", "sync", "off"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=4, help="views in the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(workload, B, V, H, W, nv_list, nf_list, P):
+    """Compulsory HBM traffic per batch: every input read once, every output written once."""
+    N = B * V
+    out = N * 3 * H * W * 4
+    if workload.startswith("mesh"):
+        mesh_in = sum(nv * 12 + nf * 24 for nv, nf in zip(nv_list, nf_list))  # faces int64 at the boundary
+        fwd = mesh_in + N * 12 + out
+        if workload == "mesh_fwd":
+            return fwd
+        return fwd + (out + mesh_in + N * 12 + N * 12)
+    return B * P * 12 + N * 12 + out
+
+
+def cpu_baseline(args, V):
+    """Oracle (port), literal RasterizeMeshesNaiveCpu loop order, single thread, bounded sample."""
+    from mvtn_amd import synthetic as syn
+    from oracle import oracle as orc
+    nviews = max(1, args.cpu_views)
+    if args.workload == "points_fwd":
+        v, f = syn.synthetic_mesh(args.tier, 0)
+        pts = syn.surface_points(v, f, 2048, 0)[None]
+        az, el, di = syn.spherical_views(20)
+        az, el, di = az[None, :nviews], el[None, :nviews], np.full((1, nviews), 1.0, np.float32)
+        t0 = time.perf_counter()
+        orc.render_points(pts, az, el, di, args.image_size, radius=0.006, mode=0, return_fragments=False)
+        dt = time.perf_counter() - t0
+        sample = "%d views of cloud seed 0 (2048 pts, %d^2), literal pixel-major loop of RasterizePointsNaiveCpu" % (nviews, args.image_size)
+    else:
+        v, f = syn.synthetic_mesh(args.tier, 0)
+        az, el, di = syn.spherical_views(V)
+        az, el, di = az[None, :nviews], el[None, :nviews], di[None, :nviews]
+        t0 = time.perf_counter()
+        orc.render_meshes([v], [f], az, el, di, args.image_size, mode=0, return_fragments=False)
+        dt = time.perf_counter() - t0
+        sample = "%d views of mesh seed 0 (tier %s, %d^2), literal pixel-major loop of RasterizeMeshesNaiveCpu + Phong (forward only)" % (
+            nviews, args.tier, args.image_size)
+    return {"value": nviews / dt, "unit": "views/s", "cores": 1, "kind": "port", "sample": sample,
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, synthetic as syn
+    lib = _lib.load()
+
+    H = W = args.image_size
+    if args.workload == "points_fwd":
+        B, V, P = args.batch or 20, args.views or 20, 2048
+    else:
+        B, V, P = args.batch or 16, args.views or 12, 0
+    az, el, di = syn.spherical_views(V)
+    if args.workload == "points_fwd":
+        di = np.full(V, 1.0, np.float32)
+    azim = torch.from_numpy(np.tile(az, (B, 1))).to(dev)
+    elev = torch.from_numpy(np.tile(el, (B, 1))).to(dev)
+    dist_t = torch.from_numpy(np.tile(di, (B, 1))).to(dev)
+    nv_list, nf_list = [], []
+    packed = points = None
+    if args.workload == "points_fwd":
+        clouds = []
+        for i in range(B):
+            v, f = syn.synthetic_mesh(args.tier, rank * B + i)
+            clouds.append(syn.surface_points(v, f, P, seed=rank * B + i))
+        points = torch.from_numpy(np.stack(clouds)).to(dev)
+        renderer = MVRenderer(V, H, pc_rendering=True, object_color="white", background_color="white",
+                              points_radius=0.006, rotation_check=args.rotation_check, strip_rows=args.strip_rows).eval()
+    else:
+        vl, fl = [], []
+        for i in range(B):
+            v, f = syn.synthetic_mesh(args.tier, rank * B + i)
+            vl.append(torch.from_numpy(v))
+            fl.append(torch.from_numpy(f))
+            nv_list.append(len(v))
+            nf_list.append(len(f))
+        packed = PackedMeshes.from_meshes(Meshes(vl, fl), dev)  # inputs resident in HBM before the timed region
+        light = "relative" if args.workload == "mesh_fwdbwd" else "fixed"
+        renderer = MVRenderer(V, H, pc_rendering=False, object_color="white", background_color="white",
+                              light_direction=light, rotation_check=args.rotation_check, strip_rows=args.strip_rows).eval()
+    if args.workload == "mesh_fwdbwd":
+        rng = np.random.default_rng(1)
+        azim = (azim + torch.from_numpy(rng.uniform(-5, 5, (B, V)).astype(np.float32)).to(dev)).requires_grad_(True)
+        elev = (elev + torch.from_numpy(rng.uniform(-5, 5, (B, V)).astype(np.float32)).to(dev)).requires_grad_(True)
+        dist_t = (dist_t + torch.from_numpy(rng.uniform(-0.1, 0.1, (B, V)).astype(np.float32)).to(dev)).requires_grad_(True)
+        gen = torch.Generator(device=dev).manual_seed(2)
+        upstream = torch.randn(B, V, 3, H, W, device=dev, generator=gen)
+
+    def step():
+        if args.workload == "mesh_fwdbwd":
+            azim.grad = elev.grad = dist_t.grad = None
+            img, _ = renderer(packed, None, azim, elev, dist_t)
+            img.backward(upstream)
+            return img
+        if args.workload == "points_fwd":
+            with torch.no_grad():
+                return renderer(None, points, azim, elev, dist_t)[0]
+        with torch.no_grad():
+            return renderer(packed, None, azim, elev, dist_t)[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_views_total = B * V * world
+    value = n_views_total * args.steps / elapsed
+
+    # ---- dominant-kernel duration, HIP events on the launch stream, same K steps ---------------------
+    kind = {"mesh_fwd": 0, "points_fwd": 1, "mesh_fwdbwd": 0}[args.workload]
+    lib.mvr_profile_begin()
+    for _ in range(args.steps):
+        out = step()
+    ms = (ctypes.c_double * 3)()
+    cnt = (ctypes.c_int32 * 3)()
+    lib.mvr_profile_end(ms, cnt)
+    torch.cuda.synchronize()
+    kern_ms = ms[kind] / max(1, cnt[kind])
+    alg = algorithmic_bytes("mesh_fwd" if args.workload == "mesh_fwdbwd" else args.workload, B, V, H, W, nv_list, nf_list, P)
+    achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": ["k_mesh_raster_shade", "k_points_raster_shade", "k_mesh_backward"][kind],
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms, "launches_timed": int(cnt[kind])}
+    if args.workload == "mesh_fwdbwd" and cnt[2] > 0:
+        roofline["backward_kernel_ms"] = ms[2] / cnt[2]
+
+    # ---- optional: the all-gather of rendered views the north_star names (not part of `value`) --------
+    gather = None
+    if dist_on and not args.no_gather:
+        from mvtn_amd.distributed import all_gather_views
+        img = out.detach()
+        for _ in range(3):
+            all_gather_views(img)
+        barrier()
+        t0 = time.perf_counter()
+        reps = max(3, min(20, args.steps))
+        for _ in range(reps):
+            step_img = step().detach()
+            all_gather_views(step_img)
+        barrier()
+        tg = time.perf_counter() - t0
+        t = torch.tensor([tg], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gather = {"views_per_s_with_allgather": n_views_total * reps / float(t.item()),
+                  "bytes_gathered_per_rank": int(img.numel() * 4 * world)}
+
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, V)
+        # second half of BASELINE.json's metric: max pixel |delta| vs the PyTorch3D-semantics oracle
+        # (first 2 objects of the batch, all views; the oracle is the checker, never the thing timed)
+        from oracle import oracle as orc
+        nb = min(2, B)
+        img = out.detach()[:nb].cpu().numpy()
+        a_, e_, d_ = (x.detach()[:nb].cpu().numpy() for x in (azim, elev, dist_t))
+        if args.workload == "points_fwd":
+            want = orc.render_points(points[:nb].cpu().numpy(), a_, e_, d_, H, radius=0.006, obj_color=(0.99999,) * 3,
+                                     bg_color=(0.99999,) * 3, return_fragments=False)
+        else:
+            vl = [packed.verts[int(packed.vert_off[i]):int(packed.vert_off[i + 1])].cpu().numpy() for i in range(nb)]
+            fl = [packed.faces[int(packed.face_off[i]):int(packed.face_off[i + 1])].cpu().numpy() for i in range(nb)]
+            ld = orc.camera_position(a_, e_, d_) if args.workload == "mesh_fwdbwd" else ((0.0, 1.0, 0.0),)
+            want = orc.render_meshes(vl, fl, a_, e_, d_, H, light_dir=ld, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3,
+                                     return_fragments=False)
+        parity = float(np.abs(img - want["images"]).max())
+
+    if rank == 0:
+        line = {
+            "metric": "rendered views/sec (224x224, 12 views/obj)" if args.workload != "points_fwd" else "rendered views/sec (224x224 point clouds, 20 views/obj)",
+            "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"mesh_fwd": "C2: B=16 tier-%s meshes x 12 spherical views, %dx%d, mesh render fwd" % (args.tier, H, W),
+                                    "mesh_fwdbwd": "C3: B=16 tier-%s meshes x 12 jittered views, %dx%d, fwd+bwd (grad wrt azim/elev/dist, relative light)" % (args.tier, H, W),
+                                    "points_fwd": "C4: B=20 clouds x 2048 pts x 20 views, %dx%d, point render fwd" % (H, W)}[args.workload],
+                       "objects_per_gpu": B, "views_per_object": V, "image_size": H, "rotation_check": args.rotation_check,
+                       "parallelism": "objects sharded over %d GPU(s), no data-path collective" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "max_pixel_err_vs_oracle": parity,
+        }
+        if gather:
+            line["allgather"] = gather
+        print(json.dumps(line))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

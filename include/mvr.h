@@ -82,7 +82,9 @@ typedef struct mvr_points_params {
   int32_t n_views;        /* V */
   int32_t image_h, image_w;
   int32_t strip_rows;     /* 0 = default */
-  float radius;           /* PointsRasterizationSettings(radius), :131 */
+  double radius;          /* PointsRasterizationSettings(radius), :131 — double: the compositor weight
+                             1 - d2/(r*r) uses r*r evaluated in double then rounded (models/renderer.py:135-145
+                             -> PointsRenderer), the rasteriser uses float(r)^2 */
   float obj_color[3];
   float bg_color[3];
 } mvr_points_params;
@@ -90,17 +92,36 @@ typedef struct mvr_points_params {
 int mvr_version(void);
 const char *mvr_last_error(void);
 
+/* Measurement aid (bench.py): between begin and end, the dominant kernel of each path is bracketed by
+ * HIP events recorded on the stream it is launched on.  mvr_profile_end synchronises on those events and
+ * returns, per kind {0: mesh raster+shade forward, 1: points raster+shade forward, 2: mesh backward},
+ * the summed kernel time in ms and the number of launches (both host arrays of length 3). */
+int mvr_profile_begin(void);
+int mvr_profile_end(double *total_ms, int32_t *launches);
+
 /* ---- cameras ----------------------------------------------------------- */
 
 /* look_at_view_transform(dist, elev, azim) in degrees, at=origin, up=+Y
  * (models/renderer.py:79-80,122-123) fused with the validity test of
  * check_valid_rotation_matrix (util.py:403-420; ops.py:156-165 is the caller):
  * view_valid[n] = 1 iff allclose(R R^T, I, atol=1e-6) and allclose(det R, 1);
- * *n_invalid = number of invalid views (written, not accumulated).
- * view_valid / n_invalid may be NULL. */
+ * status[0] = 0, status[1] = number of invalid views.  view_valid / status may be NULL. */
 int mvr_look_at(const float *azim, const float *elev, const float *dist, int32_t n,
-                float *R, float *T, int32_t *view_valid, int32_t *n_invalid,
+                float *R, float *T, int32_t *view_valid, int32_t *status /* int32[2] */,
                 mvr_stream_t stream);
+
+/* The same, fused with the remedy loop of check_and_correct_rotation_matrix (ops.py:156-165,
+ * called at models/renderer.py:81-82,124-125 with nb_trials = EXAHSTION_LIMIT = 20): while ANY view
+ * is invalid, ALL views are re-drawn as look_at(azim + 180 U, elev + 90 U', dist), U, U' ~ U[0,1)
+ * from a counter-based generator keyed by `seed`; the loop stops when every view is valid or a
+ * re-draw numbered > max_trials is still invalid (where the reference calls sys.exit).
+ * Runs entirely on the device: no host synchronisation (the reference syncs on every forward).
+ *   azim_used / elev_used (n) out: the angles R, T were finally built from (needed by the backward);
+ *   status[0] = re-draws performed, status[1] = views still invalid (non-zero <=> "Remedy did not work"). */
+int mvr_look_at_checked(const float *azim, const float *elev, const float *dist, int32_t n,
+                        int32_t max_trials, uint64_t seed, float *R, float *T, float *azim_used,
+                        float *elev_used, int32_t *view_valid, int32_t *status /* int32[2] */,
+                        mvr_stream_t stream);
 
 /* autograd backward of mvr_look_at: (dL/dR (n,9), dL/dT (n,3)) -> dL/d(azim, elev, dist) in
  * the units of the inputs (degrees).  grad_R or grad_T may be NULL (treated as zero). */

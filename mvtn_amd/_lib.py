@@ -31,7 +31,7 @@ class MeshParams(ctypes.Structure):  # struct mvr_mesh_params
 class PointsParams(ctypes.Structure):  # struct mvr_points_params
     _fields_ = [("n_clouds", ctypes.c_int32), ("n_points", ctypes.c_int32), ("n_views", ctypes.c_int32),
                 ("image_h", ctypes.c_int32), ("image_w", ctypes.c_int32), ("strip_rows", ctypes.c_int32),
-                ("radius", ctypes.c_float), ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3)]
+                ("radius", ctypes.c_double), ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3)]
 
 
 # name -> (restype, argtypes); mirrors include/mvr.h one to one
@@ -39,7 +39,10 @@ _MB, _MP, _PP = ctypes.POINTER(MeshBatch), ctypes.POINTER(MeshParams), ctypes.PO
 PROTOTYPES = {
     "mvr_version": (ctypes.c_int, []),
     "mvr_last_error": (ctypes.c_char_p, []),
+    "mvr_profile_begin": (ctypes.c_int, []),
+    "mvr_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
     "mvr_look_at": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "mvr_look_at_checked": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvr_look_at_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvr_camera_position": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     "mvr_camera_position_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]),

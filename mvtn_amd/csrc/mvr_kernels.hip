@@ -58,33 +58,86 @@ static int hip_check(hipError_t e, const char *what) {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- optional in-library kernel timing (bench.py roofline leg) -------------------------------------
+// When enabled, the dominant kernel of each path is bracketed by HIP events recorded on the SAME
+// stream it is launched on.  Disabled (the default) nothing below runs in the launch path.
+#include <vector>
+#include <utility>
+enum { PROF_MESH_FWD = 0, PROF_POINTS_FWD = 1, PROF_MESH_BWD = 2, PROF_KINDS = 3 };
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_KINDS];
+
+struct ProfScope {
+  hipStream_t st; int kind; hipEvent_t stop; bool on;
+  ProfScope(int kind_, hipStream_t st_) : st(st_), kind(kind_), stop(nullptr), on(g_prof_on) {
+    if (!on) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+    hipEventRecord(a, st);
+    stop = b;
+    g_prof_ev[kind].push_back(std::make_pair(a, b));
+  }
+  ~ProfScope() { if (on) hipEventRecord(stop, st); }
+};
+
 // ======================================================================================
 // cameras
 // ======================================================================================
 
+// counter-based uniform [0,1) (splitmix64 finaliser): no state, reproducible from (seed, trial, view, k)
+__device__ __forceinline__ float rng_uniform(unsigned long long seed, unsigned trial, unsigned i, unsigned k) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((unsigned long long)trial << 40) ^ ((unsigned long long)i << 2) ^ (unsigned long long)k);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// Single workgroup (n = B*V is hundreds to thousands).  Fuses look_at_view_transform with
+// check_valid_rotation_matrix (util.py:403-420) and, when max_trials >= 0, with the remedy loop of
+// check_and_correct_rotation_matrix (ops.py:156-165): while ANY view is invalid, ALL views are re-drawn
+// as look_at(azim + 180 U, elev + 90 U') from the ORIGINAL angles; the reference gives up
+// (sys.exit) once a re-draw numbered > max_trials is still invalid.  Running this on the device removes
+// the host synchronisation the reference pays on every forward.
+//   status[0] = re-draws performed, status[1] = views still invalid at the end.
 __global__ void __launch_bounds__(MVR_BLOCK) k_look_at(const float *__restrict__ azim, const float *__restrict__ elev,
-                                                       const float *__restrict__ dist, int n, float *__restrict__ R,
-                                                       float *__restrict__ T, int32_t *__restrict__ view_valid,
-                                                       int32_t *__restrict__ n_invalid) {
-  // single workgroup: n is B*V (hundreds to thousands)
+                                                       const float *__restrict__ dist, int n, int max_trials,
+                                                       unsigned long long seed, float *__restrict__ R,
+                                                       float *__restrict__ T, float *__restrict__ azim_used,
+                                                       float *__restrict__ elev_used, int32_t *__restrict__ view_valid,
+                                                       int32_t *__restrict__ status) {
   __shared__ int s_bad;
-  if (threadIdx.x == 0) s_bad = 0;
-  __syncthreads();
-  int bad = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float Rm[9], Tv[3];
-    mvr::look_at<float>(azim[i], elev[i], dist[i], Rm, Tv);
+  for (int trial = 0;; ++trial) {
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    int bad = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      float a = azim[i], e = elev[i];
+      if (trial > 0) {
+        a = a + 180.0f * rng_uniform(seed, trial, i, 0);
+        e = e + 90.0f * rng_uniform(seed, trial, i, 1);
+      }
+      float Rm[9], Tv[3];
+      mvr::look_at<float>(a, e, dist[i], Rm, Tv);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) R[9 * i + k] = Rm[k];
+      for (int k = 0; k < 9; ++k) R[9 * i + k] = Rm[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) T[3 * i + k] = Tv[k];
-    bool ok = mvr::rotation_valid<float>(Rm, 1e-6f);
-    if (view_valid) view_valid[i] = ok ? 1 : 0;
-    bad += ok ? 0 : 1;
+      for (int k = 0; k < 3; ++k) T[3 * i + k] = Tv[k];
+      if (azim_used) azim_used[i] = a;
+      if (elev_used) elev_used[i] = e;
+      bool ok = mvr::rotation_valid<float>(Rm, 1e-6f);
+      if (view_valid) view_valid[i] = ok ? 1 : 0;
+      bad += ok ? 0 : 1;
+    }
+    if (bad) atomicAdd(&s_bad, bad);
+    __syncthreads();
+    const int nb = s_bad;
+    __syncthreads();
+    if (nb == 0 || max_trials < 0 || trial > max_trials) {
+      if (threadIdx.x == 0 && status) { status[0] = trial; status[1] = nb; }
+      break;
+    }
   }
-  if (bad) atomicAdd(&s_bad, bad);
-  __syncthreads();
-  if (threadIdx.x == 0 && n_invalid) *n_invalid = s_bad;
 }
 
 __global__ void __launch_bounds__(MVR_BLOCK) k_look_at_bwd(const float *__restrict__ azim, const float *__restrict__ elev,
@@ -140,7 +193,10 @@ struct MeshPtrs {
 
 // grid (ceil(max_faces / BLOCK), B): one lane per face; area-weighted face normal
 // n_f = cross(v2 - v1, v0 - v1) added to its three vertices (Meshes.verts_normals_packed).
-__global__ void __launch_bounds__(MVR_BLOCK) k_normals_accum(MeshPtrs m, float4 *__restrict__ vattr) {
+// The sum is accumulated in 64-bit fixed point (2^-32 units): integer adds commute, so the
+// result is bit-reproducible run to run (float atomics would depend on arrival order).
+#define MVR_FIX_SCALE 4294967296.0f
+__global__ void __launch_bounds__(MVR_BLOCK) k_normals_accum(MeshPtrs m, long long *__restrict__ nacc) {
   int b = blockIdx.y;
   int f0 = m.face_off[b], nf = m.face_off[b + 1] - f0, v0 = m.vert_off[b];
   int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,21 +207,29 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_normals_accum(MeshPtrs m, float4 
   f3 e0 = {pc[0] - pb[0], pc[1] - pb[1], pc[2] - pb[2]};
   f3 e1 = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
   f3 n = mvr::cross(e0, e1);
-  float *d0 = (float *)&vattr[2 * (size_t)(v0 + i0) + 1];
-  float *d1 = (float *)&vattr[2 * (size_t)(v0 + i1) + 1];
-  float *d2 = (float *)&vattr[2 * (size_t)(v0 + i2) + 1];
-  atomicAdd(d0, n.x); atomicAdd(d0 + 1, n.y); atomicAdd(d0 + 2, n.z);
-  atomicAdd(d1, n.x); atomicAdd(d1 + 1, n.y); atomicAdd(d1 + 2, n.z);
-  atomicAdd(d2, n.x); atomicAdd(d2 + 1, n.y); atomicAdd(d2 + 2, n.z);
+  // clamp keeps the conversion defined for absurdly large meshes (|n| < 2^30 after scaling by 2^32 needs |n| < 2^-2 * 2^32)
+  const float lim = 1.0e9f;
+  long long qx = __float2ll_rn(fminf(fmaxf(n.x, -lim), lim) * MVR_FIX_SCALE);
+  long long qy = __float2ll_rn(fminf(fmaxf(n.y, -lim), lim) * MVR_FIX_SCALE);
+  long long qz = __float2ll_rn(fminf(fmaxf(n.z, -lim), lim) * MVR_FIX_SCALE);
+  unsigned long long *d0 = (unsigned long long *)(nacc + 3 * (size_t)(v0 + i0));
+  unsigned long long *d1 = (unsigned long long *)(nacc + 3 * (size_t)(v0 + i1));
+  unsigned long long *d2 = (unsigned long long *)(nacc + 3 * (size_t)(v0 + i2));
+  atomicAdd(d0, (unsigned long long)qx); atomicAdd(d0 + 1, (unsigned long long)qy); atomicAdd(d0 + 2, (unsigned long long)qz);
+  atomicAdd(d1, (unsigned long long)qx); atomicAdd(d1 + 1, (unsigned long long)qy); atomicAdd(d1 + 2, (unsigned long long)qz);
+  atomicAdd(d2, (unsigned long long)qx); atomicAdd(d2 + 1, (unsigned long long)qy); atomicAdd(d2 + 2, (unsigned long long)qz);
 }
 
 // one lane per vertex: normalise the accumulated normal (eps 1e-6) and store the position beside it.
 __global__ void __launch_bounds__(MVR_BLOCK) k_vattr_finalize(const float *__restrict__ verts, int total_verts,
+                                                              const long long *__restrict__ nacc,
                                                               float4 *__restrict__ vattr, float *__restrict__ normals_out) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= total_verts) return;
-  float4 acc = vattr[2 * (size_t)v + 1];
-  f3 n = mvr::normalize<float>({acc.x, acc.y, acc.z}, mvr::kNormalizeEps);
+  const double inv = 1.0 / 4294967296.0;
+  f3 a = {(float)((double)nacc[3 * (size_t)v] * inv), (float)((double)nacc[3 * (size_t)v + 1] * inv),
+          (float)((double)nacc[3 * (size_t)v + 2] * inv)};
+  f3 n = mvr::normalize<float>(a, mvr::kNormalizeEps);
   vattr[2 * (size_t)v] = make_float4(verts[3 * (size_t)v], verts[3 * (size_t)v + 1], verts[3 * (size_t)v + 2], 0.f);
   vattr[2 * (size_t)v + 1] = make_float4(n.x, n.y, n.z, 0.f);
   if (normals_out) {
@@ -695,6 +759,7 @@ static int default_strip_rows(int H, int W) {
 }
 
 struct MeshWs {
+  long long *nacc;   // 3 * total_verts fixed-point normal sums
   float4 *vattr;     // 2 * total_verts
   float4 *proj;      // V * total_verts
   float *partials;   // N * n_strips * 18
@@ -707,6 +772,7 @@ static MeshWs mesh_ws_layout(const mvr_mesh_batch *m, const mvr_mesh_params *p, 
   int n_strips = (p->image_h + TH - 1) / TH;
   size_t N = (size_t)m->n_meshes * p->n_views;
   size_t off = 0;
+  w.nacc = (long long *)((char *)base + off); off += align_up((size_t)3 * m->total_verts * sizeof(long long), 256);
   w.vattr = (float4 *)((char *)base + off); off += align_up((size_t)2 * m->total_verts * sizeof(float4), 256);
   w.proj = (float4 *)((char *)base + off); off += align_up((size_t)p->n_views * m->total_verts * sizeof(float4), 256);
   w.partials = (float *)((char *)base + off); off += align_up(N * n_strips * MVR_NACC * sizeof(float), 256);
@@ -729,13 +795,46 @@ static int check_mesh_args(const mvr_mesh_batch *m, const mvr_mesh_params *p) {
 extern "C" {
 
 int mvr_version(void) { return 100; }
+
+int mvr_profile_begin(void) {
+  for (int k = 0; k < PROF_KINDS; ++k) {
+    for (auto &p : g_prof_ev[k]) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    g_prof_ev[k].clear();
+  }
+  g_prof_on = true;
+  return MVR_OK;
+}
+
+int mvr_profile_end(double *total_ms, int32_t *launches) {
+  g_prof_on = false;
+  for (int k = 0; k < PROF_KINDS; ++k) {
+    double sum = 0.0;
+    int cnt = 0;
+    for (auto &p : g_prof_ev[k]) {
+      float ms = 0.f;
+      if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { sum += ms; ++cnt; }
+      hipEventDestroy(p.first); hipEventDestroy(p.second);
+    }
+    g_prof_ev[k].clear();
+    if (total_ms) total_ms[k] = sum;
+    if (launches) launches[k] = cnt;
+  }
+  return MVR_OK;
+}
 const char *mvr_last_error(void) { return g_err; }
 
-int mvr_look_at(const float *azim, const float *elev, const float *dist, int32_t n, float *R, float *T,
-                int32_t *view_valid, int32_t *n_invalid, mvr_stream_t stream) {
+int mvr_look_at_checked(const float *azim, const float *elev, const float *dist, int32_t n, int32_t max_trials,
+                        uint64_t seed, float *R, float *T, float *azim_used, float *elev_used, int32_t *view_valid,
+                        int32_t *status, mvr_stream_t stream) {
   if (!azim || !elev || !dist || !R || !T || n <= 0) return set_err(MVR_ERR_INVALID_ARG, "mvr_look_at: bad argument");
-  hipLaunchKernelGGL(k_look_at, dim3(1), dim3(MVR_BLOCK), 0, (hipStream_t)stream, azim, elev, dist, n, R, T, view_valid, n_invalid);
+  hipLaunchKernelGGL(k_look_at, dim3(1), dim3(MVR_BLOCK), 0, (hipStream_t)stream, azim, elev, dist, n, max_trials,
+                     (unsigned long long)seed, R, T, azim_used, elev_used, view_valid, status);
   return hip_check(hipGetLastError(), "k_look_at");
+}
+
+int mvr_look_at(const float *azim, const float *elev, const float *dist, int32_t n, float *R, float *T,
+                int32_t *view_valid, int32_t *status, mvr_stream_t stream) {
+  return mvr_look_at_checked(azim, elev, dist, n, -1, 0ull, R, T, nullptr, nullptr, view_valid, status, stream);
 }
 
 int mvr_look_at_backward(const float *azim, const float *elev, const float *dist, int32_t n, const float *grad_R,
@@ -770,20 +869,22 @@ size_t mvr_mesh_workspace_bytes(const mvr_mesh_batch *meshes, const mvr_mesh_par
 
 static int launch_vattr(const mvr_mesh_batch *m, const MeshWs &ws, float *normals_out, hipStream_t st) {
   MeshPtrs mp = {m->verts, m->faces, m->vert_off, m->face_off, m->vert_colors, m->n_meshes};
-  HIP_TRY(hipMemsetAsync(ws.vattr, 0, (size_t)2 * m->total_verts * sizeof(float4), st));
-  hipLaunchKernelGGL(k_normals_accum, dim3((m->max_faces + MVR_BLOCK - 1) / MVR_BLOCK, m->n_meshes), dim3(MVR_BLOCK), 0, st, mp, ws.vattr);
+  HIP_TRY(hipMemsetAsync(ws.nacc, 0, (size_t)3 * m->total_verts * sizeof(long long), st));
+  hipLaunchKernelGGL(k_normals_accum, dim3((m->max_faces + MVR_BLOCK - 1) / MVR_BLOCK, m->n_meshes), dim3(MVR_BLOCK), 0, st, mp, ws.nacc);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_vattr_finalize, dim3((m->total_verts + MVR_BLOCK - 1) / MVR_BLOCK), dim3(MVR_BLOCK), 0, st, m->verts,
-                     m->total_verts, ws.vattr, normals_out);
+                     m->total_verts, ws.nacc, ws.vattr, normals_out);
   return hip_check(hipGetLastError(), "k_vattr_finalize");
 }
 
 int mvr_vertex_normals(const mvr_mesh_batch *meshes, float *normals, void *workspace, size_t workspace_bytes, mvr_stream_t stream) {
   if (!meshes || !normals || !workspace) return set_err(MVR_ERR_INVALID_ARG, "mvr_vertex_normals: bad argument");
-  if (workspace_bytes < align_up((size_t)2 * meshes->total_verts * sizeof(float4), 256))
+  size_t nacc_b = align_up((size_t)3 * meshes->total_verts * sizeof(long long), 256);
+  if (workspace_bytes < nacc_b + align_up((size_t)2 * meshes->total_verts * sizeof(float4), 256))
     return set_err(MVR_ERR_WORKSPACE, "mvr_vertex_normals: workspace too small");
   MeshWs ws;
-  ws.vattr = (float4 *)workspace;
+  ws.nacc = (long long *)workspace;
+  ws.vattr = (float4 *)((char *)workspace + nacc_b);
   return launch_vattr(meshes, ws, normals, (hipStream_t)stream);
 }
 
@@ -822,7 +923,10 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_raster_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int grid = 8 * a.views_per_xcd * n_strips;
-  hipLaunchKernelGGL(k_mesh_raster_shade, dim3(grid), dim3(MVR_BLOCK), lds, st, a);
+  {
+    ProfScope prof(PROF_MESH_FWD, st);
+    hipLaunchKernelGGL(k_mesh_raster_shade, dim3(grid), dim3(MVR_BLOCK), lds, st, a);
+  }
   return hip_check(hipGetLastError(), "k_mesh_raster_shade");
 }
 
@@ -852,7 +956,10 @@ int mvr_render_meshes_backward(const mvr_mesh_batch *meshes, const mvr_mesh_para
   a.ambient = params->ambient; a.diffuse = params->diffuse; a.specular = params->specular; a.shininess = params->shininess;
   for (int k = 0; k < 3; ++k) a.obj[k] = params->obj_color[k];
   int grid = 8 * a.views_per_xcd * n_strips;
-  hipLaunchKernelGGL(k_mesh_backward, dim3(grid), dim3(MVR_BLOCK), 0, st, a);
+  {
+    ProfScope prof(PROF_MESH_BWD, st);
+    hipLaunchKernelGGL(k_mesh_backward, dim3(grid), dim3(MVR_BLOCK), 0, st, a);
+  }
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_mesh_backward_finalize, dim3((N + MVR_BLOCK - 1) / MVR_BLOCK), dim3(MVR_BLOCK), 0, st, ws.partials, N,
                      n_strips, R, T, grad_R, grad_T, grad_light);
@@ -874,7 +981,7 @@ static int check_points_args(const mvr_points_params *p) {
   if (!p) return set_err(MVR_ERR_INVALID_ARG, "null points params");
   if (p->n_clouds <= 0 || p->n_points <= 0 || p->n_views <= 0 || p->image_h <= 0 || p->image_w <= 0)
     return set_err(MVR_ERR_INVALID_ARG, "bad points params");
-  if (!(p->radius > 0.f)) return set_err(MVR_ERR_INVALID_ARG, "radius must be > 0");
+  if (!(p->radius > 0.0)) return set_err(MVR_ERR_INVALID_ARG, "radius must be > 0");
   if (p->image_h > 32767 || p->image_w > 32767) return set_err(MVR_ERR_UNSUPPORTED, "image side > 32767");
   return MVR_OK;
 }
@@ -890,14 +997,17 @@ int mvr_render_points_forward(const mvr_points_params *p, const float *points, c
   a.points = points; a.colors = point_colors; a.R = R; a.T = T; a.dist = dist; a.images = images; a.p2p = pix_to_point;
   a.B = p->n_clouds; a.P = p->n_points; a.V = p->n_views; a.N = a.B * a.V; a.H = p->image_h; a.W = p->image_w;
   a.TH = points_strip_rows(p); a.n_strips = (a.H + a.TH - 1) / a.TH; a.views_per_xcd = (a.N + 7) / 8;
-  a.radius = p->radius; a.r2 = p->radius * p->radius; a.r2w = (float)((double)p->radius * (double)p->radius);
+  a.radius = (float)p->radius; a.r2 = a.radius * a.radius; a.r2w = (float)(p->radius * p->radius);
   for (int k = 0; k < 3; ++k) { a.obj[k] = p->obj_color[k]; a.bg[k] = p->bg_color[k]; }
   size_t lds = (size_t)a.TH * a.W * 8 + (size_t)(a.W + a.TH) * 4 + 16;
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)k_points_raster_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int grid = 8 * a.views_per_xcd * a.n_strips;
-  hipLaunchKernelGGL(k_points_raster_shade, dim3(grid), dim3(MVR_BLOCK), lds, (hipStream_t)stream, a);
+  {
+    ProfScope prof(PROF_POINTS_FWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_points_raster_shade, dim3(grid), dim3(MVR_BLOCK), lds, (hipStream_t)stream, a);
+  }
   return hip_check(hipGetLastError(), "k_points_raster_shade");
 }
 
@@ -915,7 +1025,7 @@ int mvr_render_points_backward(const mvr_points_params *p, const float *points, 
   a.partials = (float *)workspace;
   a.B = p->n_clouds; a.P = p->n_points; a.V = p->n_views; a.N = a.B * a.V; a.H = p->image_h; a.W = p->image_w;
   a.TH = points_strip_rows(p); a.n_strips = (a.H + a.TH - 1) / a.TH; a.views_per_xcd = (a.N + 7) / 8;
-  a.r2w = (float)((double)p->radius * (double)p->radius);
+  a.r2w = (float)(p->radius * p->radius);
   for (int k = 0; k < 3; ++k) a.obj[k] = p->obj_color[k];
   hipStream_t st = (hipStream_t)stream;
   int grid = 8 * a.views_per_xcd * a.n_strips;

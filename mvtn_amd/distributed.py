@@ -1,0 +1,76 @@
+"""Multi-GPU: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+The path shards by OBJECT: every (b, v) view is independent (models/renderer.py:65-151 has no
+cross-view term) and a mesh's V views stay on the rank that holds the mesh, so mesh bytes never
+cross the fabric and the backward needs no exchange (gradients are per-(b,v) scalars).  The only
+collective is the all-gather of rendered views for consumers that want the whole batch on every
+rank; its autograd backward is the matching reduce-scatter.  The reference itself is single-GPU
+(run_mvtn.py:56-57,87).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_objects, world_size, rank):
+    """Contiguous [lo, hi) slice of the object axis for `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_objects, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_counts(n_objects, world_size):
+    return [shard_range(n_objects, world_size, r)[1] - shard_range(n_objects, world_size, r)[0] for r in range(world_size)]
+
+
+class _AllGatherViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, local, counts, group):
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        ctx.counts, ctx.group, ctx.rank = counts, group, rank
+        local = local.contiguous()
+        if len(set(counts)) == 1:
+            out = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))
+            dist.all_gather_into_tensor(out, local, group=group)
+            return out
+        parts = [local.new_empty((c,) + tuple(local.shape[1:])) for c in counts]
+        dist.all_gather(parts, local, group=group)
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        counts, group, rank = ctx.counts, ctx.group, ctx.rank
+        g = g.contiguous()
+        if len(set(counts)) == 1:
+            out = g.new_empty((counts[0],) + tuple(g.shape[1:]))
+            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=group)
+            return out, None, None
+        parts = [p.contiguous() for p in torch.split(g, counts, 0)]
+        out = torch.empty_like(parts[rank])
+        dist.reduce_scatter(out, parts, op=dist.ReduceOp.SUM, group=group)
+        return out, None, None
+
+
+def all_gather_views(local_images, counts=None, group=None):
+    """(B_local, V, 3, H, W) on every rank -> (B, V, 3, H, W) on every rank, object order = rank order.
+    Differentiable: backward is reduce-scatter(sum) of the incoming gradient."""
+    world = dist.get_world_size(group)
+    if counts is None:
+        counts = [local_images.shape[0]] * world
+    return _AllGatherViews.apply(local_images, list(counts), group)
+
+
+def render_sharded(renderer, meshes, points, azim, elev, dist_, color=None, gather=True, group=None):
+    """Render this rank's shard of a batch that every rank holds in full (meshes: list of B objects;
+    points / azim / elev / dist: leading dimension B), optionally all-gathering the images.
+    Returns (images, cameras_of_the_local_shard)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = azim.shape[0]
+    lo, hi = shard_range(B, world, rank)
+    m = None if meshes is None else ([meshes[i] for i in range(lo, hi)] if not hasattr(meshes, "n_meshes") else meshes)
+    p = None if points is None else points[lo:hi]
+    c = color[lo:hi] if (torch.is_tensor(color) and color.dim() >= 2) else color
+    images, cams = renderer(m, p, azim[lo:hi], elev[lo:hi], dist_[lo:hi], c)
+    if gather:
+        images = all_gather_views(images, shard_counts(B, world), group)
+    return images, cams

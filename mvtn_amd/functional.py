@@ -32,17 +32,26 @@ def _ptr(t):
 
 class _LookAt(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, azim, elev, dist):
+    def forward(ctx, azim, elev, dist, max_trials, seed):
         lib = _lib.load()
         azim, elev, dist = _f32c(azim), _f32c(elev), _f32c(dist)
         _require_cuda(azim, elev, dist)
         n = azim.numel()
-        R = torch.empty(n, 3, 3, dtype=torch.float32, device=azim.device)
-        T = torch.empty(n, 3, dtype=torch.float32, device=azim.device)
-        status = torch.empty(n + 1, dtype=torch.int32, device=azim.device)  # [0] = #invalid, [1:] per-view valid
-        _lib.check(lib.mvr_look_at(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), n, R.data_ptr(), T.data_ptr(),
-                                   status[1:].data_ptr(), status.data_ptr(), _stream()), "mvr_look_at")
-        ctx.save_for_backward(azim, elev, dist)
+        dev = azim.device
+        R = torch.empty(n, 3, 3, dtype=torch.float32, device=dev)
+        T = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        status = torch.empty(n + 2, dtype=torch.int32, device=dev)  # [0] re-draws, [1] #invalid, [2:] per-view valid
+        if max_trials >= 0:
+            used = torch.empty(2, n, dtype=torch.float32, device=dev)
+            _lib.check(lib.mvr_look_at_checked(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), n, int(max_trials),
+                                               int(seed) & 0xFFFFFFFFFFFFFFFF, R.data_ptr(), T.data_ptr(), used[0].data_ptr(),
+                                               used[1].data_ptr(), status[2:].data_ptr(), status.data_ptr(), _stream()),
+                       "mvr_look_at_checked")
+            ctx.save_for_backward(used[0], used[1], dist)
+        else:
+            _lib.check(lib.mvr_look_at(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), n, R.data_ptr(), T.data_ptr(),
+                                       status[2:].data_ptr(), status.data_ptr(), _stream()), "mvr_look_at")
+            ctx.save_for_backward(azim, elev, dist)
         ctx.mark_non_differentiable(status)
         return R, T, status
 
@@ -56,17 +65,17 @@ class _LookAt(torch.autograd.Function):
         ga, ge, gd = torch.empty_like(azim), torch.empty_like(elev), torch.empty_like(dist)
         _lib.check(lib.mvr_look_at_backward(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), n, _ptr(gR), _ptr(gT),
                                             ga.data_ptr(), ge.data_ptr(), gd.data_ptr(), _stream()), "mvr_look_at_backward")
-        return ga, ge, gd
+        return ga, ge, gd, None, None
 
 
-def look_at_view_transform(dist, elev, azim, return_status=False):
+def look_at_view_transform(dist, elev, azim, return_status=False, max_trials=-1, seed=0):
     """R (N,3,3), T (N,3) for flat per-view (N,) distance / elevation / azimuth in degrees —
     pytorch3d look_at_view_transform as called at models/renderer.py:79-80 — differentiable.
-    status[0] = number of views failing check_valid_rotation_matrix (util.py:403-420),
-    status[1:] = per-view validity; both computed on the device without a host sync."""
-    shape = azim.shape
-    R, T, status = _LookAt.apply(azim.reshape(-1), elev.reshape(-1), dist.reshape(-1))
-    assert len(shape) == 1
+    status (int32, N+2): [0] = remedy re-draws performed, [1] = number of views failing
+    check_valid_rotation_matrix (util.py:403-420), [2:] = per-view validity; all computed on the
+    device without a host sync.  max_trials >= 0 enables the device-side remedy loop of
+    ops.py:156-165 (see mvr_look_at_checked in include/mvr.h)."""
+    R, T, status = _LookAt.apply(azim.reshape(-1), elev.reshape(-1), dist.reshape(-1), max_trials, seed)
     return (R, T, status) if return_status else (R, T)
 
 
@@ -162,6 +171,35 @@ def render_meshes(packed: PackedMeshes, R, T, light_dir, params):
     plus the re-layout of :109-113; differentiable w.r.t. R, T and a per-view light_dir."""
     need_grad = torch.is_grad_enabled() and (R.requires_grad or T.requires_grad or light_dir.requires_grad)
     return _RenderMeshes.apply(R, T, light_dir, packed, params, need_grad)
+
+
+def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params):
+    """(images, pix_to_face (N,H,W) int32 LOCAL face index / -1) without autograd — for parity tests."""
+    lib = _lib.load()
+    R, T, light = _f32c(R), _f32c(T), _f32c(light_dir)
+    _require_cuda(R, T, light, packed.verts)
+    B, V, H, W = packed.n_meshes, params.n_views, params.image_h, params.image_w
+    mb = packed.c_struct()
+    ws_bytes = lib.mvr_mesh_workspace_bytes(mb, params)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=R.device)
+    images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=R.device)
+    p2f = torch.empty(B * V, H, W, dtype=torch.int32, device=R.device)
+    _lib.check(lib.mvr_render_meshes_forward(mb, params, R.data_ptr(), T.data_ptr(), light.data_ptr(), images.data_ptr(),
+                                             p2f.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "mvr_render_meshes_forward")
+    return images, p2f
+
+
+def render_points_fragments(points, colors, R, T, dist, params):
+    """(images, pix_to_point (N,H,W) int32) without autograd — for parity tests."""
+    lib = _lib.load()
+    R, T, dist = _f32c(R), _f32c(T), _f32c(dist)
+    B, V, H, W = params.n_clouds, params.n_views, params.image_h, params.image_w
+    images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=R.device)
+    p2p = torch.empty(B * V, H, W, dtype=torch.int32, device=R.device)
+    _lib.check(lib.mvr_render_points_forward(params, points.data_ptr(), _ptr(colors), R.data_ptr(), T.data_ptr(),
+                                             dist.data_ptr(), images.data_ptr(), p2p.data_ptr(), None, 0, _stream()),
+               "mvr_render_points_forward")
+    return images, p2p
 
 
 def vertex_normals(packed: PackedMeshes):

@@ -6,10 +6,15 @@ PyTorch3D calls are replaced by hand-written gfx950 HIP kernels behind include/m
 Extra keyword-only constructor arguments (defaults reproduce the reference + PyTorch3D 0.7.x):
   perspective_correct  PyTorch3D's RasterizationSettings.perspective_correct (None->True for
                        perspective cameras since 0.5; 0.4 used False)        [SURVEY App. A.9(i)]
-  rotation_check       "sync": reference behaviour — after enqueueing the render, read the device-side
-                       validity count (one host sync, as check_valid_rotation_matrix costs the
-                       reference, util.py:417-420) and run the random-perturbation remedy of
-                       ops.py:156-165 if any R is invalid;  "off": skip the read (no host sync).
+  rotation_check       how check_and_correct_rotation_matrix (ops.py:156-165) is honoured:
+                       "device" (default): validity test AND the random re-draw remedy run inside the
+                           look-at kernel — no host synchronisation; the reference's
+                           sys.exit("Remedy did not work") is raised by the NEXT forward (or by
+                           check_status()) once the asynchronously copied status word has landed;
+                       "sync": reference-style — read the device-side validity count right after
+                           enqueueing the render (one host sync per forward, as util.py:417-420 costs
+                           the reference) and run the remedy from the host with torch's RNG;
+                       "off": compute the flags but never read them.
 """
 import sys
 
@@ -28,7 +33,7 @@ EXAHSTION_LIMIT = 20  # models/renderer.py:30 (the reference's spelling)
 class MVRenderer(nn.Module):
     def __init__(self, nb_views, image_size=224, pc_rendering=True, object_color="white", background_color="white",
                  faces_per_pixel=1, points_radius=0.006, points_per_pixel=1, light_direction="random",
-                 cull_backfaces=False, *, perspective_correct=True, rotation_check="sync", strip_rows=0):
+                 cull_backfaces=False, *, perspective_correct=True, rotation_check="device", strip_rows=0):
         super().__init__()
         self.nb_views = nb_views
         self.image_size = image_size
@@ -41,9 +46,11 @@ class MVRenderer(nn.Module):
         self.light_direction_type = light_direction
         self.cull_backfaces = cull_backfaces
         self.perspective_correct = perspective_correct
-        if rotation_check not in ("sync", "off"):
-            raise ValueError("rotation_check must be 'sync' or 'off'")
+        if rotation_check not in ("device", "sync", "off"):
+            raise ValueError("rotation_check must be 'device', 'sync' or 'off'")
         self.rotation_check = rotation_check
+        self._calls = 0
+        self._pending = []  # (event, pinned status copy) of earlier forwards, "device" mode
         self.strip_rows = strip_rows
         # faces_per_pixel > 1 does not change a HardPhongShader image (hard_rgb_blend reads only
         # the nearest face), so any value >= 1 renders identically; points_per_pixel > 1 would.
@@ -71,16 +78,44 @@ class MVRenderer(nn.Module):
 
     # -- look_at + ops.py:156-165 check_and_correct_rotation_matrix ----------------------------
     def _cameras(self, azim, elev, dist):
+        """R, T, status for the (B,V) angle tensors; "device" mode runs the remedy in the kernel."""
+        if self.rotation_check == "device":
+            self.check_status(block=False)
+            self._calls += 1
+            seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+            R, T, status = F.look_at_view_transform(flatten_views(dist), flatten_views(elev), flatten_views(azim),
+                                                    return_status=True, max_trials=EXAHSTION_LIMIT, seed=seed)
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(status[:2], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((ev, host))
+            return R, T, status
         return F.look_at_view_transform(flatten_views(dist), flatten_views(elev), flatten_views(azim), return_status=True)
 
+    def check_status(self, block=True):
+        """Raise the reference's sys.exit("Remedy did not work") if an earlier forward exhausted the
+        device-side remedy.  block=False only looks at status words that have already landed."""
+        keep = []
+        for ev, host in self._pending:
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                keep.append((ev, host))
+                continue
+            if int(host[1]) != 0:
+                self._pending = []
+                sys.exit("Remedy did not work")
+        self._pending = keep
+
     def _remedy(self, azim, elev, dist):
-        """Random re-draw of ALL views until every R is valid (ops.py:156-165)."""
+        """Host-driven random re-draw of ALL views until every R is valid (ops.py:156-165), "sync" mode."""
         exhastion = 0
         while True:
             exhastion += 1
-            R, T, status = self._cameras(azim + 180.0 * torch.rand_like(azim), elev + 90.0 * torch.rand_like(elev), dist)
-            bad = int(status[0].item())
-            if bad == 0:
+            R, T, status = F.look_at_view_transform(flatten_views(dist), flatten_views(elev + 90.0 * torch.rand_like(elev)),
+                                                    flatten_views(azim + 180.0 * torch.rand_like(azim)), return_status=True)
+            if int(status[1].item()) == 0:
                 return R, T
             if exhastion > EXAHSTION_LIMIT:
                 sys.exit("Remedy did not work")
@@ -109,7 +144,7 @@ class MVRenderer(nn.Module):
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (packed.n_meshes, self.nb_views))
         R, T, status = self._cameras(azim, elev, dist)
         images = F.render_meshes(packed, R, T, light, params)
-        if self.rotation_check == "sync" and int(status[0].item()) != 0:
+        if self.rotation_check == "sync" and int(status[1].item()) != 0:
             R, T = self._remedy(azim, elev, dist)
             images = F.render_meshes(packed, R, T, light, params)
         return images, Cameras(R, T, "perspective")
@@ -131,7 +166,7 @@ class MVRenderer(nn.Module):
         flat_dist = flatten_views(dist)
         R, T, status = self._cameras(azim, elev, dist)
         images = F.render_points(pts, colors, R, T, flat_dist, params)
-        if self.rotation_check == "sync" and int(status[0].item()) != 0:
+        if self.rotation_check == "sync" and int(status[1].item()) != 0:
             R, T = self._remedy(azim, elev, dist)
             images = F.render_points(pts, colors, R, T, flat_dist, params)
         return images, Cameras(R, T, "orthographic", znear=0.01)

@@ -1,0 +1,340 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star): pixel -> face / pixel -> point maps bit-exact; images within
+1e-4 max abs error (fp32) — observed error is ~1e-6 (pow by squaring vs powf, atomic-order of the
+normal accumulation); camera matrices bit-exact; gradients vs fp64 finite differences of the
+oracle within 2e-3 relative (fp32 accumulation over thousands of pixels).
+"""
+import numpy as np
+import pytest
+import torch
+
+from mvtn_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+TOL_PIXEL = 1e-4  # north_star tolerance
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test needs a GPU"
+    return torch.device("cuda:0")
+
+
+def _t(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(_dev())
+
+
+def _mesh_batch(specs):
+    vl, fl = [], []
+    for tier, seed in specs:
+        v, f = syn.cad_soup(seed) if tier == "soup" else syn.synthetic_mesh(tier, seed)
+        vl.append(v)
+        fl.append(f)
+    return vl, fl
+
+
+def _views(B, V, seed, jitter=True):
+    az, el, di = syn.spherical_views(V)
+    az, el, di = np.tile(az, (B, 1)), np.tile(el, (B, 1)), np.tile(di, (B, 1))
+    if jitter:
+        rng = np.random.default_rng(seed)
+        az = az + rng.uniform(-5, 5, az.shape)
+        el = el + rng.uniform(-5, 5, el.shape)
+        di = di + rng.uniform(-0.1, 0.1, di.shape)
+    return az.astype(np.float32), el.astype(np.float32), di.astype(np.float32)
+
+
+def test_look_at_bit_exact(oracle):
+    from mvtn_amd import functional as F
+    rng = np.random.default_rng(0)
+    az = rng.uniform(-360, 360, 500).astype(np.float32)
+    el = rng.uniform(-89, 89, 500).astype(np.float32)
+    di = rng.uniform(0.5, 4, 500).astype(np.float32)
+    az[:4], el[:4] = [0, 90, 180, 270], [0, 0, 0, 0]
+    el[4:8] = [90, -90, 89.9999, -90.0]  # degenerate: invalid R (KA10)
+    R, T, status = F.look_at_view_transform(_t(di), _t(el), _t(az), return_status=True)
+    Ro, To = oracle.look_at(az, el, di)
+    assert np.array_equal(R.cpu().numpy(), Ro)
+    assert np.array_equal(T.cpu().numpy(), To)
+    ok, flags = oracle.check_rotation(Ro)
+    assert np.array_equal(status[2:].cpu().numpy().astype(bool), flags)
+    assert int(status[0]) == 0 and int(status[1]) == int((~flags).sum()) and int(status[1]) >= 1
+    C = F.camera_position_from_spherical_angles(_t(di), _t(el), _t(az))
+    assert np.array_equal(C.cpu().numpy(), oracle.camera_position(az, el, di))
+
+
+def test_vertex_normals(oracle):
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = _mesh_batch([("S", 0), ("M", 1), ("soup", 2)])
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    got = F.vertex_normals(packed).cpu().numpy()
+    want = np.concatenate([oracle.vertex_normals(v, f) for v, f in zip(vl, fl)], 0)
+    # float atomics: accumulation order differs from the sequential index_add
+    assert np.abs(got - want).max() < 2e-5
+
+
+@pytest.mark.parametrize("size,specs,V,persp,cull,light,strip", [
+    (128, [("M", 0)], 4, True, False, "fixed", 0),                                  # C1
+    (224, [("M", 0), ("M", 1)], 12, True, False, "fixed", 0),                       # C2 slice
+    (224, [("S", 3), ("L", 4), ("soup", 5), ("M", 6)], 6, True, False, "relative", 0),  # ragged + CAD soup
+    (224, [("M", 7), ("soup", 8)], 4, False, True, "fixed", 0),                     # 0.4-style switches
+    (96, [("S", 9)], 3, True, False, "fixed", 5),                                   # odd strip height
+    (37, [("S", 10), ("soup", 11)], 2, True, True, "relative", 0),                  # odd image size
+])
+def test_mesh_forward_parity(oracle, size, specs, V, persp, cull, light, strip):
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = _mesh_batch(specs)
+    B = len(vl)
+    az, el, di = _views(B, V, seed=len(specs) + V) if V in (4, 6, 12, 20) else _views(B, 4, 1)
+    az, el, di = az[:, :V], el[:, :V], di[:, :V]
+    if size == 128:  # C1: the reference's own circular configuration
+        a, e, d = syn.circular_views(4, 30.0, 2.2)
+        az, el, di = a[None], e[None], d[None]
+    obj, bg = (0.99999, 0.99999, 0.99999), (0.99999, 0.99999, 0.99999)
+    ldir = oracle.camera_position(az, el, di) if light == "relative" else np.array([[0.0, 1.0, 0.0]], np.float32)
+    want = oracle.render_meshes(vl, fl, az, el, di, size, light_dir=ldir, obj_color=obj, bg_color=bg,
+                                perspective_correct=persp, cull_backfaces=cull, mode=1)
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    params = F.mesh_params(V, size, ldir.shape[0], obj, bg, cull_backfaces=cull, perspective_correct=persp, strip_rows=strip)
+    img, p2f = F.render_meshes_fragments(packed, R, T, _t(ldir), params)
+    torch.cuda.synchronize()
+    p2f, img = p2f.cpu().numpy(), img.cpu().numpy()
+    n_diff = int((p2f != want["pix_to_face"]).sum())
+    err = float(np.abs(img - want["images"]).max())
+    print("coverage mismatches: %d  max|d|: %.3g  covered: %.3f" % (n_diff, err, (p2f >= 0).mean()))
+    assert n_diff == 0, "pixel->face map differs from the oracle at %d pixels" % n_diff
+    assert err <= TOL_PIXEL
+    assert img.shape == (B, V, 3, size, size)
+
+
+def test_mesh_custom_vertex_colors(oracle):
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = _mesh_batch([("S", 0), ("M", 1)])
+    rng = np.random.default_rng(0)
+    mx = max(len(v) for v in vl)
+    col = rng.uniform(0, 1, (2, mx, 3)).astype(np.float32)
+    vc = np.concatenate([col[b, :len(v)] for b, v in enumerate(vl)], 0)
+    az, el, di = _views(2, 4, 3)
+    want = oracle.render_meshes(vl, fl, az, el, di, 64, vert_colors=vc, bg_color=(0, 0, 0))
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev(), vert_colors=torch.from_numpy(col))
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    params = F.mesh_params(4, 64, 1, (1, 1, 1), (0, 0, 0))
+    img, p2f = F.render_meshes_fragments(packed, R, T, _t([[0, 1, 0]]), params)
+    assert np.array_equal(p2f.cpu().numpy(), want["pix_to_face"])
+    assert np.abs(img.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+
+
+def _fd_grad_full(oracle, vl, fl, az, el, di, size, G, p2f, relative, persp, h=1e-5):
+    """fp64 central differences of L = sum(G * image) w.r.t. (azim, elev, dist), pix_to_face fixed."""
+    vl64 = [v.astype(np.float64) for v in vl]
+
+    def L(a, e, d):
+        ld = oracle.camera_position(a, e, d, np.float64) if relative else np.array([[0.0, 1.0, 0.0]])
+        o = oracle.render_meshes(vl64, fl, a, e, d, size, light_dir=ld, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3,
+                                 perspective_correct=persp, dtype=np.float64, fixed_p2f=p2f, return_fragments=False)
+        return float((o["images"] * G).sum())
+
+    base = [az.astype(np.float64), el.astype(np.float64), di.astype(np.float64)]
+    grads = []
+    for k in range(3):
+        g = np.zeros(base[k].shape)
+        for idx in np.ndindex(*base[k].shape):
+            p = [x.copy() for x in base]
+            m = [x.copy() for x in base]
+            p[k][idx] += h
+            m[k][idx] -= h
+            g[idx] = (L(*p) - L(*m)) / (2 * h)
+        grads.append(g)
+    return grads
+
+
+@pytest.mark.parametrize("light,persp", [("relative", True), ("fixed", True), ("relative", False)])
+def test_mvrenderer_mesh_forward_backward(oracle, light, persp):
+    """End-to-end through the nn.Module + autograd, against fp64 finite differences (KA9)."""
+    from mvtn_amd import MVRenderer, Meshes
+    vl, fl = _mesh_batch([("S", 0), ("M", 1)])
+    B, V, size = 2, 3, 64
+    az, el, di = _views(B, 4, 5)
+    az, el, di = az[:, :V], el[:, :V], di[:, :V]
+    r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white",
+                   light_direction=light, perspective_correct=persp).eval()
+    meshes = [Meshes([v], [f]) for v, f in zip(vl, fl)]
+    ta, te, td = (_t(x).requires_grad_(True) for x in (az, el, di))
+    images, cams = r(meshes, None, ta, te, td)
+    assert images.shape == (B, V, 3, size, size) and cams.R.shape == (B * V, 3, 3)
+    ldir = oracle.camera_position(az, el, di) if light == "relative" else np.array([[0.0, 1.0, 0.0]], np.float32)
+    want = oracle.render_meshes(vl, fl, az, el, di, size, light_dir=ldir, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3,
+                                perspective_correct=persp)
+    assert np.abs(images.detach().cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+    rng = np.random.default_rng(2)
+    G = rng.normal(size=images.shape)
+    images.backward(_t(G))
+    fd = _fd_grad_full(oracle, vl, fl, az, el, di, size, G, want["pix_to_face"], light == "relative", persp)
+    for name, got, ref in zip(("azim", "elev", "dist"), (ta.grad, te.grad, td.grad), fd):
+        got = got.cpu().numpy().astype(np.float64)
+        scale = np.abs(ref).max() + 1e-12
+        rel = np.abs(got - ref).max() / scale
+        print(name, "rel err", rel, "scale", scale)
+        assert rel < 2e-3, (name, got, ref)
+
+
+@pytest.mark.parametrize("size,B,P,V,dist,strip", [(224, 3, 2048, 20, 1.0, 0), (224, 2, 2048, 4, 2.2, 0), (128, 2, 512, 4, 1.0, 7),
+                                                   (45, 1, 300, 3, 0.8, 0)])
+def test_points_forward_parity(oracle, size, B, P, V, dist, strip):
+    from mvtn_amd import functional as F
+    vl, fl = _mesh_batch([("M", s) for s in range(B)])
+    pts = np.stack([syn.surface_points(v, f, P, seed=i) for i, (v, f) in enumerate(zip(vl, fl))])
+    az, el, di = syn.spherical_views(V) if V in (4, 20) else syn.circular_views(V)
+    az, el = np.tile(az, (B, 1)), np.tile(el, (B, 1))
+    di = np.full((B, V), dist, np.float32)
+    obj, bg = (0.99999,) * 3, (0.99999, 0.5, 0.25)
+    want = oracle.render_points(pts, az, el, di, size, radius=0.006 if size >= 128 else 0.03, obj_color=obj, bg_color=bg)
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    params = F.points_params(B, P, V, size, 0.006 if size >= 128 else 0.03, obj, bg, strip_rows=strip)
+    img, idx = F.render_points_fragments(_t(pts), None, R, T, _t(di.reshape(-1)), params)
+    idx, img = idx.cpu().numpy(), img.cpu().numpy()
+    n_diff = int((idx != want["idx"]).sum())
+    err = float(np.abs(img - want["images"]).max())
+    print("idx mismatches %d, max|d| %.3g, covered %.4f" % (n_diff, err, (idx >= 0).mean()))
+    assert n_diff == 0 and err <= 1e-6
+
+
+def test_points_colors_and_module(oracle):
+    from mvtn_amd import MVRenderer
+    B, P, V, size = 2, 1024, 4, 128
+    vl, fl = _mesh_batch([("M", 0), ("M", 1)])
+    pts = np.stack([syn.surface_points(v, f, P, seed=i) for i, (v, f) in enumerate(zip(vl, fl))])
+    az, el, di = syn.spherical_views(V)
+    az, el, di = np.tile(az, (B, 1)), np.tile(el, (B, 1)), np.full((B, V), 1.0, np.float32)
+    r = MVRenderer(V, size, pc_rendering=True, object_color="red", background_color="black", points_radius=0.02).eval()
+    ta, te, td = (_t(x).requires_grad_(True) for x in (az, el, di))
+    images, cams = r(None, torch.from_numpy(pts), ta, te, td)
+    want = oracle.render_points(pts, az, el, di, size, radius=0.02, obj_color=(1.0 / 1.00001, 0, 0), bg_color=(0, 0, 0))
+    assert np.abs(images.detach().cpu().numpy() - want["images"]).max() <= 1e-6
+    # KA8: K=1 norm-weighted compositing has exactly zero gradient away from the 1e-4 weight clamp
+    w = 1 - want["dist2"] / np.float32(0.02 * 0.02)
+    clamped = (want["idx"] >= 0) & (w < 1e-4)
+    G = np.ones(images.shape, np.float32).reshape(B * V, 3, size, size)
+    G[np.broadcast_to(clamped[:, None], G.shape)] = 0
+    images.backward(_t(G.reshape(images.shape)))
+    assert float(ta.grad.abs().max()) == 0 and float(te.grad.abs().max()) == 0 and float(td.grad.abs().max()) == 0
+
+
+def test_points_backward_clamp_region(oracle):
+    """A point whose weight falls below the compositor's 1e-4 clamp has a non-zero gradient;
+    check it against fp64 finite differences of the oracle (fixed pixel->point map)."""
+    from mvtn_amd import functional as F
+    size, r = 32, 0.05
+    # camera on +z looking at the origin: view x = -world x ... solve numerically instead of by hand
+    az, el, di = np.array([[20.0]], np.float32), np.array([[10.0]], np.float32), np.array([[1.3]], np.float32)
+    R64, T64 = oracle.look_at(az, el, di, np.float64)
+    # want view-space (x, y) = pixel centre (i=10, j=12) + offset of length sqrt(r^2 (1 - 5e-5)) ; world = ((view - T) R^T) * dist
+    cx, cy = -1 + (2 * 10 + 1) / size, -1 + (2 * 12 + 1) / size
+    off = np.sqrt(r * r * (1 - 5e-5))
+    view = np.array([cx + off * 0.6, cy + off * 0.8, 1.1])
+    world = ((view - T64[0]) @ R64[0].T) * float(di[0, 0])
+    pts = np.array([[world, [5.0, 5.0, 5.0]]], np.float32)  # second point far outside the frustum
+    want = oracle.render_points(pts, az, el, di, size, radius=r, obj_color=(0.7, 0.8, 0.9), bg_color=(0, 0, 0))
+    hit = np.argwhere(want["idx"][0] == 0)
+    w = 1 - want["dist2"][0][want["idx"][0] == 0] / (r * r)
+    assert len(hit) >= 1 and (w < 1e-4).any(), "test construction: expected a clamped pixel"
+    ta, te, td = (_t(x.reshape(-1)).requires_grad_(True) for x in (az, el, di))
+    Rt, Tt = F.look_at_view_transform(td, te, ta)
+    params = F.points_params(1, 2, 1, size, r, (0.7, 0.8, 0.9), (0, 0, 0))
+    img = F.render_points(_t(pts), None, Rt, Tt, td, params)
+    assert np.abs(img.detach().cpu().numpy() - want["images"]).max() <= 1e-6
+    rng = np.random.default_rng(0)
+    G = rng.normal(size=img.shape)
+    img.backward(_t(G))
+    pts64 = pts.astype(np.float64)
+
+    def L(a, e, d):
+        o = oracle.render_points(pts64, a, e, d, size, radius=r, obj_color=(0.7, 0.8, 0.9), bg_color=(0, 0, 0),
+                                 dtype=np.float64, fixed_idx=want["idx"], return_fragments=False)
+        return float((o["images"] * G).sum())
+    h = 1e-7
+    base = [az.astype(np.float64), el.astype(np.float64), di.astype(np.float64)]
+    for k, (name, got) in enumerate(zip(("azim", "elev", "dist"), (ta.grad, te.grad, td.grad))):
+        p = [x.copy() for x in base]
+        m = [x.copy() for x in base]
+        p[k][0, 0] += h
+        m[k][0, 0] -= h
+        ref = (L(*p) - L(*m)) / (2 * h)
+        got = float(got.cpu().numpy().reshape(-1)[0])
+        print(name, got, ref)
+        assert abs(got - ref) <= 2e-2 * abs(ref) + 1e-3
+
+
+@pytest.mark.parametrize("mode", ["device", "sync"])
+def test_rotation_remedy(mode):
+    """ops.py:156-165: an invalid R (elev = 89.9999; exactly 90 is repaired inside look_at) triggers a
+    random re-draw of ALL views; the render then uses valid cameras and gradients still flow."""
+    from mvtn_amd import MVRenderer, Meshes
+    from mvtn_amd.helpers import check_valid_rotation_matrix
+    v, f = syn.synthetic_mesh("S", 0)
+    az, el, di = _t([[0.0, 90.0]]).requires_grad_(True), _t([[89.9999, 30.0]]).requires_grad_(True), _t([[2.2, 2.2]])
+    torch.manual_seed(0)
+    r = MVRenderer(2, 32, pc_rendering=False, light_direction="fixed", rotation_check=mode).eval()
+    images, cams = r([Meshes([v], [f])], None, az, el, di)
+    assert check_valid_rotation_matrix(cams.R)
+    assert torch.isfinite(images).all()
+    images.sum().backward()
+    assert torch.isfinite(az.grad).all() and torch.isfinite(el.grad).all()
+    if mode == "device":
+        r.check_status()  # no exhaustion -> no exit
+    r_off = MVRenderer(2, 32, pc_rendering=False, light_direction="fixed", rotation_check="off").eval()
+    images2, cams2 = r_off([Meshes([v], [f])], None, az.detach(), el.detach(), di)
+    assert not check_valid_rotation_matrix(cams2.R)
+    assert not torch.equal(images2, images)
+
+
+def test_rotation_remedy_device_statistics():
+    """The device-side re-draw follows ops.py:160-161: every view moves by azim + U[0,180), elev + U[0,90)."""
+    from mvtn_amd import functional as F
+    n = 512
+    az, el, di = _t(np.zeros(n)), _t(np.concatenate([[89.9999], np.zeros(n - 1)])), _t(np.full(n, 2.2))
+    lib_out = F._LookAt.apply(az, el, di, 20, 1234)
+    R, T, status = lib_out
+    assert int(status[0]) >= 1 and int(status[1]) == 0
+    # recover the angles actually used from the camera centres: C = -R T
+    C = -torch.bmm(R, T[:, :, None])[:, :, 0].cpu().numpy().astype(np.float64)
+    elev_used = np.degrees(np.arcsin(C[:, 1] / 2.2))
+    azim_used = np.degrees(np.arctan2(C[:, 0], C[:, 2])) % 360
+    if int(status[0]) == 1:
+        assert 0 <= azim_used.min() and azim_used.max() < 180.01
+        assert abs(azim_used.mean() - 90) < 10 and abs(np.delete(elev_used, 0).mean() - 45) < 5
+    # a different seed gives a different draw; the same seed reproduces it
+    R2, _, _ = F._LookAt.apply(az, el, di, 20, 1234)
+    R3, _, _ = F._LookAt.apply(az, el, di, 20, 99)
+    assert torch.equal(R, R2) and not torch.equal(R, R3)
+
+
+def test_full_size_properties():
+    """BASELINE config C2 at full size (B=16, V=12, 224^2): size-independent properties —
+    determinism, background constant, silhouette fraction of a unit sphere (KA2), views of the
+    same mesh from mirrored azimuths are mirror images in coverage count."""
+    from mvtn_amd import MVRenderer, Meshes
+    B, V = 16, 12
+    meshes = [Meshes([v], [f]) for v, f in (syn.synthetic_mesh("M", s) for s in range(B))]
+    az, el, di = syn.spherical_views(V)
+    ta, te, td = (_t(np.tile(x, (B, 1))) for x in (az, el, di))
+    r = MVRenderer(V, 224, pc_rendering=False, light_direction="fixed", rotation_check="off").eval()
+    a, _ = r(meshes, None, ta, te, td)
+    b, _ = r(meshes, None, ta, te, td)
+    assert a.shape == (B, V, 3, 224, 224)
+    assert torch.equal(a, b), "render is not deterministic"
+    bg = np.float32(1.0) / np.float32(1.00001)
+    assert float(a.max()) <= 1.0 + 1e-6 and float(a.min()) >= 0.49
+    assert (a == float(bg)).float().mean() > 0.3  # background pixels are exactly 0.99999 (KA6)
+    # KA2: unit sphere at d = 2.2, fov 60: silhouette radius 0.88388 NDC -> 61.36 % of the image
+    vs, fs = syn.icosphere(5)
+    sph = [Meshes([torch.from_numpy(vs.astype(np.float32))], [torch.from_numpy(fs)])]
+    r1 = MVRenderer(1, 224, pc_rendering=False, light_direction="fixed", background_color="black", rotation_check="off").eval()
+    img, _ = r1(sph, None, _t([[30.0]]), _t([[20.0]]), _t([[2.2]]))
+    frac = float((img[0, 0].sum(0) > 0).float().mean())
+    assert abs(frac - 0.6136) < 0.004, frac
