@@ -59,7 +59,8 @@ _LIB = None
 
 
 def lib_path():
-    return _build.LIB_PATH
+    # MVR_LIB: developer override used by tools/ (diagnostic builds); the default is the in-tree product library
+    return os.environ.get("MVR_LIB") or _build.LIB_PATH
 
 
 def load():

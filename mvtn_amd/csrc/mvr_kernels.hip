@@ -34,8 +34,8 @@ typedef V3<float> f3;
 
 #define MVR_BLOCK 256
 #define MVR_WAVES (MVR_BLOCK / 64)
-#define MVR_CHUNK 1024          // faces scanned per round (MVR_CHUNK / MVR_BLOCK per thread)
-#define MVR_SMALL_MAX 32        // bbox pixels (within the strip) up to which a face is "small"
+#define MVR_LIST_CAP 3072       // LDS face list (4 B entries): flushed before a worst-case scan round (2048) could overflow it
+#define MVR_SMALL_MAX 64        // bbox pixels (within the strip) up to which a face is "small"
 #define MVR_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define MVR_NACC 18
 
@@ -73,11 +73,11 @@ struct ProfScope {
     if (!on) return;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-    hipEventRecord(a, st);
+    (void)hipEventRecord(a, st);
     stop = b;
     g_prof_ev[kind].push_back(std::make_pair(a, b));
   }
-  ~ProfScope() { if (on) hipEventRecord(stop, st); }
+  ~ProfScope() { if (on) (void)hipEventRecord(stop, st); }
 };
 
 // ======================================================================================
@@ -220,6 +220,47 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_normals_accum(MeshPtrs m, long lo
   atomicAdd(d2, (unsigned long long)qx); atomicAdd(d2 + 1, (unsigned long long)qy); atomicAdd(d2 + 2, (unsigned long long)qz);
 }
 
+// Whole mesh in ONE workgroup when its 3 x int64 per-vertex accumulators fit in LDS (<= MVR_NRM_LDS_VERTS
+// vertices): faces -> 64-bit LDS atomics -> barrier -> normalise -> vattr.  One launch, no memset, no global
+// atomics; same fixed-point sum as the 3-step global path, hence the same bits.
+#define MVR_NRM_BLOCK 1024
+#define MVR_NRM_LDS_VERTS 6400   // 6400 * 24 B = 150 KiB
+__global__ void __launch_bounds__(MVR_NRM_BLOCK) k_vattr_mesh_lds(MeshPtrs m, float4 *__restrict__ vattr,
+                                                                  float *__restrict__ normals_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned long long *acc = (unsigned long long *)smem;
+  const int b = blockIdx.x;
+  const int f0 = m.face_off[b], nf = m.face_off[b + 1] - f0, v0 = m.vert_off[b], nv = m.vert_off[b + 1] - v0;
+  for (int i = threadIdx.x; i < 3 * nv; i += MVR_NRM_BLOCK) acc[i] = 0ull;
+  __syncthreads();
+  const float lim = 1.0e9f;
+  for (int f = threadIdx.x; f < nf; f += MVR_NRM_BLOCK) {
+    const int32_t *fc = m.faces + 3 * (size_t)(f0 + f);
+    int i0 = fc[0], i1 = fc[1], i2 = fc[2];
+    const float *pa = m.verts + 3 * (size_t)(v0 + i0), *pb = m.verts + 3 * (size_t)(v0 + i1), *pc = m.verts + 3 * (size_t)(v0 + i2);
+    f3 e0 = {pc[0] - pb[0], pc[1] - pb[1], pc[2] - pb[2]};
+    f3 e1 = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+    f3 n = mvr::cross(e0, e1);
+    unsigned long long qx = (unsigned long long)__float2ll_rn(fminf(fmaxf(n.x, -lim), lim) * MVR_FIX_SCALE);
+    unsigned long long qy = (unsigned long long)__float2ll_rn(fminf(fmaxf(n.y, -lim), lim) * MVR_FIX_SCALE);
+    unsigned long long qz = (unsigned long long)__float2ll_rn(fminf(fmaxf(n.z, -lim), lim) * MVR_FIX_SCALE);
+    atomicAdd(acc + 3 * i0, qx); atomicAdd(acc + 3 * i0 + 1, qy); atomicAdd(acc + 3 * i0 + 2, qz);
+    atomicAdd(acc + 3 * i1, qx); atomicAdd(acc + 3 * i1 + 1, qy); atomicAdd(acc + 3 * i1 + 2, qz);
+    atomicAdd(acc + 3 * i2, qx); atomicAdd(acc + 3 * i2 + 1, qy); atomicAdd(acc + 3 * i2 + 2, qz);
+  }
+  __syncthreads();
+  const double inv = 1.0 / 4294967296.0;
+  for (int i = threadIdx.x; i < nv; i += MVR_NRM_BLOCK) {
+    f3 a = {(float)((double)(long long)acc[3 * i] * inv), (float)((double)(long long)acc[3 * i + 1] * inv),
+            (float)((double)(long long)acc[3 * i + 2] * inv)};
+    f3 n = mvr::normalize<float>(a, mvr::kNormalizeEps);
+    size_t v = (size_t)v0 + i;
+    vattr[2 * v] = make_float4(m.verts[3 * v], m.verts[3 * v + 1], m.verts[3 * v + 2], 0.f);
+    vattr[2 * v + 1] = make_float4(n.x, n.y, n.z, 0.f);
+    if (normals_out) { normals_out[3 * v] = n.x; normals_out[3 * v + 1] = n.y; normals_out[3 * v + 2] = n.z; }
+  }
+}
+
 // one lane per vertex: normalise the accumulated normal (eps 1e-6) and store the position beside it.
 __global__ void __launch_bounds__(MVR_BLOCK) k_vattr_finalize(const float *__restrict__ verts, int total_verts,
                                                               const long long *__restrict__ nacc,
@@ -263,8 +304,85 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_project_verts(MeshPtrs m, int V, 
 // mesh: rasterise + shade, one workgroup per (view, strip)
 // ======================================================================================
 
+#ifdef MVR_DIAG
+// diagnostic build only (tools/diag_phases.py): per-workgroup phase timestamps, written to a buffer of
+// their own; never compiled into libmvr_hip.so.
+__device__ unsigned long long *g_diag = nullptr;
+#define DIAG_STAMP(slot) do { if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] = clock64(); } while (0)
+#define DIAG_ADD(slot, v) do { if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] += (v); } while (0)
+#else
+#define DIAG_STAMP(slot)
+#define DIAG_ADD(slot, v)
+#endif
+
+__device__ __forceinline__ f3 ld3(const float4 *p) { float4 t = *p; return {t.x, t.y, t.z}; }
+
+// Pixel-index range (NDC index space, i = S-1-col) whose centres c_i = -1 + (2i+1)/S can satisfy
+// lo <= c_i <= hi.  c_i >= lo  <=>  i >= (lo+1) S/2 - 1/2 in exact arithmetic; the float evaluation of
+// that bound and of c_i itself are each off by < S * 2.4e-7 pixel, so a margin of 1e-3 + 2e-6 S pixel
+// keeps the range conservative (never drops a pixel the exact bbox test would accept) while adding
+// at most one extra column/row.  The exact IEEE bbox test still runs per pixel.
+__device__ __forceinline__ void ndc_range(float lo, float hi, int S, int *i0, int *i1) {
+  const float m = 1e-3f + 2e-6f * (float)S;
+  float a = (lo + 1.0f) * (0.5f * (float)S) - 0.5f;
+  float b = (hi + 1.0f) * (0.5f * (float)S) - 0.5f;
+  a = fminf(fmaxf(a, -2.0f), (float)S + 2.0f);
+  b = fminf(fmaxf(b, -2.0f), (float)S + 2.0f);
+  int x0 = (int)ceilf(a - m), x1 = (int)floorf(b + m);
+  *i0 = x0 < 0 ? 0 : x0;
+  *i1 = x1 > S - 1 ? S - 1 : x1;
+}
+
+// ======================================================================================
+// mesh: per (view, face) strip range — the rasteriser's scan reads 2 bytes per face instead of
+// gathering 3 indices + 3 projected vertices per face per strip
+// ======================================================================================
+
+#define MVR_BIN_NONE 0xFFFFu   // face can touch no pixel of this view (culled / off-screen)
+
+// grid (ceil(max_faces / BLOCK), N).  bins[n * stride + f] = g0 | (g1 << 8): first / last row-bin (G image rows
+// each, G a multiple of the strip height chosen so that there are <= 254 bins) that the face's bounding box
+// can reach; conservative (ndc_range).  Rows of the table are padded to `stride` (multiple of 8) entries so
+// that the rasteriser reads them as aligned 16-byte vectors.
+__global__ void __launch_bounds__(MVR_BLOCK) k_face_bins(MeshPtrs m, int V, int H, int W, int G, int stride, int cull_backfaces,
+                                                         const float4 *__restrict__ proj_all, unsigned short *__restrict__ bins) {
+  const int n = blockIdx.y;
+  const int b = n / V, v = n - b * V;
+  const int vo = m.vert_off[b], nv = m.vert_off[b + 1] - vo;
+  const int fo = m.face_off[b], nf = m.face_off[b + 1] - fo;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  (void)fo;
+  const float4 *__restrict__ proj = proj_all + (size_t)V * vo + (size_t)v * nv;
+  const int32_t *__restrict__ fc = m.faces + 3 * (size_t)(fo + f);
+  const f3 v0 = ld3(proj + fc[0]), v1 = ld3(proj + fc[1]), v2 = ld3(proj + fc[2]);
+  // the per-face culls of mvr::face_setup (without its reciprocal)
+  const float xmin = fminf(fminf(v0.x, v1.x), v2.x), xmax = fmaxf(fmaxf(v0.x, v1.x), v2.x);
+  const float ymin = fminf(fminf(v0.y, v1.y), v2.y), ymax = fmaxf(fmaxf(v0.y, v1.y), v2.y);
+  const float zmin = fminf(fminf(v0.z, v1.z), v2.z), zmax = fmaxf(fmaxf(v0.z, v1.z), v2.z);
+  const float face_area = mvr::edge_fn(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+  const bool zero_area = (face_area <= mvr::kEps && face_area >= -mvr::kEps);
+  bool ok = !(zmax < 0.f || (cull_backfaces && face_area < 0.f) || zmin < mvr::kEps || zero_area);
+  // NaN coordinates fail every comparison below -> not drawable (the exact test would reject every pixel too)
+  ok = ok && xmax >= mvr::pix_to_ndc<float>(0, W) && xmin <= mvr::pix_to_ndc<float>(W - 1, W) &&
+       ymax >= mvr::pix_to_ndc<float>(0, H) && ymin <= mvr::pix_to_ndc<float>(H - 1, H);
+  unsigned short out = MVR_BIN_NONE;
+  if (ok) {
+    int x0, x1, y0, y1;
+    ndc_range(xmin, xmax, W, &x0, &x1);
+    ndc_range(ymin, ymax, H, &y0, &y1);
+    if (x0 <= x1 && y0 <= y1) {
+      int g0 = (H - 1 - y1) / G, g1 = (H - 1 - y0) / G;  // NDC row index jy <-> image row H-1-jy
+      out = (unsigned short)(g0 | (g1 << 8));
+    }
+  }
+  bins[(size_t)n * stride + f] = out;
+}
+
 struct RasterArgs {
   MeshPtrs m;
+  const unsigned short *bins;
+  int bin_rows, bin_stride;
   const float4 *proj;
   const float4 *vattr;
   const float *R, *T, *light;
@@ -285,17 +403,26 @@ __device__ __forceinline__ void decode_block(int bid, int n_strips, int views_pe
   *strip = j % n_strips;
 }
 
-__device__ __forceinline__ f3 ld3(const float4 *p) { float4 t = *p; return {t.x, t.y, t.z}; }
+// Face classification by the number of candidate pixels (bbox ∩ strip): entries are appended to an
+// LDS list — small faces from the front, large faces from the back.
+__device__ __forceinline__ int classify_face(const mvr::FaceSetup<float> &fs, int W, int H, int jy_lo, int jy_hi,
+                                             float px_min, float px_max, float py_min, float py_max,
+                                             int *x0, int *x1, int *y0, int *y1) {
+  // a pixel passes the bbox test iff xmin <= px <= xmax and ymin <= py <= ymax
+  bool hit = fs.drawable && fs.ymax >= py_min && fs.ymin <= py_max && fs.xmax >= px_min && fs.xmin <= px_max;
+  if (!hit) return 0;
+  ndc_range(fs.xmin, fs.xmax, W, x0, x1);
+  ndc_range(fs.ymin, fs.ymax, H, y0, y1);
+  *y0 = max(*y0, jy_lo); *y1 = min(*y1, jy_hi);
+  if (*x0 > *x1 || *y0 > *y1) return 0;
+  int count = (*x1 - *x0 + 1) * (*y1 - *y0 + 1);
+  return count <= MVR_SMALL_MAX ? 1 : 2;
+}
 
-// conservative pixel-index range (in NDC index space i = S-1-col) of [lo, hi]
-__device__ __forceinline__ void ndc_range(float lo, float hi, int S, int *i0, int *i1) {
-  float a = (lo + 1.0f) * (0.5f * (float)S) - 0.5f;
-  float b = (hi + 1.0f) * (0.5f * (float)S) - 0.5f;
-  a = fminf(fmaxf(a, -2.0f), (float)S + 2.0f);
-  b = fminf(fmaxf(b, -2.0f), (float)S + 2.0f);
-  int x0 = (int)floorf(a) - 1, x1 = (int)ceilf(b) + 1;
-  *i0 = x0 < 0 ? 0 : x0;
-  *i1 = x1 > S - 1 ? S - 1 : x1;
+__device__ __forceinline__ mvr::FaceSetup<float> load_face(const float4 *__restrict__ proj, const int32_t *__restrict__ faces,
+                                                          int f, bool cull) {
+  int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+  return mvr::face_setup<float>(ld3(proj + i0), ld3(proj + i1), ld3(proj + i2), cull);
 }
 
 __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
@@ -304,8 +431,8 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
   unsigned long long *keys = (unsigned long long *)smem;                 // TH * W
   float *px_tab = (float *)(keys + (size_t)TH * W);                      // W   (index = NDC index i)
   float *py_tab = px_tab + W;                                            // TH  (index = jy - jy_lo)
-  int *list = (int *)(py_tab + TH);                                      // 3 * MVR_CHUNK
-  int *cnt = list + 3 * MVR_CHUNK;                                       // [0] small, [1] large
+  int *list = (int *)(py_tab + TH);                                      // MVR_LIST_CAP face indices (bit 31: large)
+  int *cnt = list + MVR_LIST_CAP;                                        // [0] entries
 
   int n, strip;
   decode_block(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
@@ -314,72 +441,73 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
   const int b = n / a.V, v = n - b * a.V;
   const int vo = a.m.vert_off[b], nv = a.m.vert_off[b + 1] - vo;
   const int fo = a.m.face_off[b], nf = a.m.face_off[b + 1] - fo;
-  const float4 *proj = a.proj + (size_t)a.V * vo + (size_t)v * nv;
-  const int32_t *faces = a.m.faces + 3 * (size_t)fo;
+  const float4 *__restrict__ proj = a.proj + (size_t)a.V * vo + (size_t)v * nv;
+  const int32_t *__restrict__ faces = a.m.faces + 3 * (size_t)fo;
+  const unsigned short *__restrict__ bins = a.bins + (size_t)n * a.bin_stride;
   const int r0 = strip * TH;
   const int rows = min(TH, H - r0);
   const int jy_hi = H - 1 - r0, jy_lo = jy_hi - (rows - 1);  // NDC row indices covered by the strip
+  const unsigned g_lo = (unsigned)(r0 / a.bin_rows), g_hi = (unsigned)((r0 + rows - 1) / a.bin_rows);
   const bool persp = (a.flags & MVR_PERSPECTIVE_CORRECT) != 0;
   const bool cull = (a.flags & MVR_CULL_BACKFACES) != 0;
 
   for (int i = tid; i < rows * W; i += MVR_BLOCK) keys[i] = MVR_KEY_EMPTY;
   for (int i = tid; i < W; i += MVR_BLOCK) px_tab[i] = mvr::pix_to_ndc<float>(i, W);
   for (int i = tid; i < rows; i += MVR_BLOCK) py_tab[i] = mvr::pix_to_ndc<float>(jy_lo + i, H);
-  if (tid < 2) cnt[tid] = 0;
+  if (tid == 0) cnt[0] = 0;
   __syncthreads();
   const float py_min = py_tab[0], py_max = py_tab[rows - 1];
   const float px_min = px_tab[0], px_max = px_tab[W - 1];
 
-  for (int base = 0; base < nf; base += MVR_CHUNK) {
-    // ---- scan: cull + bbox test, compact into the LDS list --------------------------
-#pragma unroll 1
-    for (int k = 0; k < MVR_CHUNK / MVR_BLOCK; ++k) {
-      int f = base + k * MVR_BLOCK + tid;
-      int kind = 0;  // 0 none, 1 small, 2 large
-      int xr = 0, yr = 0;
-      if (f < nf) {
-        int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
-        mvr::FaceSetup<float> fs = mvr::face_setup<float>(ld3(proj + i0), ld3(proj + i1), ld3(proj + i2), cull);
-        // a pixel passes the bbox test iff xmin <= px <= xmax and ymin <= py <= ymax
-        bool hit = fs.drawable && fs.ymax >= py_min && fs.ymin <= py_max && fs.xmax >= px_min && fs.xmin <= px_max;
-        if (hit) {
-          int x0, x1, y0, y1;
-          ndc_range(fs.xmin, fs.xmax, W, &x0, &x1);
-          ndc_range(fs.ymin, fs.ymax, H, &y0, &y1);
-          y0 = max(y0, jy_lo); y1 = min(y1, jy_hi);
-          if (x0 <= x1 && y0 <= y1) {
-            int count = (x1 - x0 + 1) * (y1 - y0 + 1);
-            kind = count <= MVR_SMALL_MAX ? 1 : 2;
-            xr = x0 | (x1 << 16); yr = y0 | (y1 << 16);
-          }
-        }
+  DIAG_STAMP(0);
+#ifdef MVR_DIAG
+  unsigned long long t_scan = 0, t_small = 0, t_large = 0, n_small_tot = 0, n_large_tot = 0;
+  unsigned long long tc0 = clock64();
+#endif
+  for (int base = 0; base < nf; base += MVR_BLOCK * 8) {
+    // ---- scan: 8 faces (one 16-byte vector of row-bin ranges) per lane; compact hits into the LDS list ----
+    const int f0 = base + tid * 8;
+    unsigned hit = 0;
+    if (f0 < nf) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(bins + f0);
+      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+        unsigned e0 = e & 0xffu, e1 = e >> 8;
+        bool h = (e != MVR_BIN_NONE) && e0 <= g_hi && e1 >= g_lo && (f0 + k) < nf;
+        hit |= (h ? 1u : 0u) << k;
       }
-      unsigned long long ms = __ballot(kind == 1), ml = __ballot(kind == 2);
-      int bs = 0, bl = 0;
-      if (lane == 0) {
-        if (ms) bs = atomicAdd(&cnt[0], __popcll(ms));
-        if (ml) bl = atomicAdd(&cnt[1], __popcll(ml));
-      }
-      bs = __shfl(bs, 0); bl = __shfl(bl, 0);
-      unsigned long long below = (1ull << lane) - 1ull;
-      if (kind == 1) {
-        int e = bs + __popcll(ms & below);
-        list[3 * e] = f; list[3 * e + 1] = xr; list[3 * e + 2] = yr;
-      } else if (kind == 2) {
-        int e = MVR_CHUNK - 1 - (bl + __popcll(ml & below));
-        list[3 * e] = f; list[3 * e + 1] = xr; list[3 * e + 2] = yr;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool h = (hit >> k) & 1u;
+      unsigned long long mh = __ballot(h);
+      if (mh) {  // wave-uniform
+        int bs = 0;
+        if (lane == 0) bs = atomicAdd(&cnt[0], __popcll(mh));
+        bs = __shfl(bs, 0);
+        if (h) list[bs + __popcll(mh & ((1ull << lane) - 1ull))] = f0 + k;
       }
     }
     __syncthreads();
-    const int n_small = cnt[0], n_large = cnt[1];
-    // ---- small faces: one lane per face ------------------------------------------------
-    for (int e = tid; e < n_small; e += MVR_BLOCK) {
-      int f = list[3 * e], xr = list[3 * e + 1], yr = list[3 * e + 2];
-      int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
-      mvr::FaceSetup<float> fs = mvr::face_setup<float>(ld3(proj + i0), ld3(proj + i1), ld3(proj + i2), cull);
-      int x0 = xr & 0xffff, x1 = xr >> 16, y0 = yr & 0xffff, y1 = yr >> 16;
+    const int n_list = cnt[0];
+    const bool last = base + MVR_BLOCK * 8 >= nf;
+    if (!last && n_list + MVR_BLOCK * 8 <= MVR_LIST_CAP) continue;  // room for another worst-case scan round
+#ifdef MVR_DIAG
+    unsigned long long tc1 = clock64();
+    t_scan += tc1 - tc0; n_small_tot += n_list;
+#endif
+    // ---- small faces: one lane per face; faces with many candidate pixels are only marked ------
+    for (int e = tid; e < n_list; e += MVR_BLOCK) {
+      const int f = list[e];
+      mvr::FaceSetup<float> fs = load_face(proj, faces, f, cull);
+      int x0, x1, y0, y1;
+      const int kind = classify_face(fs, W, H, jy_lo, jy_hi, px_min, px_max, py_min, py_max, &x0, &x1, &y0, &y1);
+      if (kind == 2) { list[e] = f | (int)0x80000000; continue; }
+      if (kind == 0) continue;
       for (int jy = y0; jy <= y1; ++jy) {
-        float py = py_tab[jy - jy_lo];
+        const float py = py_tab[jy - jy_lo];
         unsigned long long *krow = keys + (size_t)(jy_hi - jy) * W + (W - 1);
         for (int ix = x0; ix <= x1; ++ix) {
           float pz, w0, w1, w2;
@@ -390,31 +518,53 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
         }
       }
     }
-    // ---- large faces: one wave per face, lanes stride over the bbox --------------------
-    for (int j = wave; j < n_large; j += MVR_WAVES) {
-      int e = MVR_CHUNK - 1 - j;
-      int f = list[3 * e], xr = list[3 * e + 1], yr = list[3 * e + 2];
-      int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
-      mvr::FaceSetup<float> fs = mvr::face_setup<float>(ld3(proj + i0), ld3(proj + i1), ld3(proj + i2), cull);
-      int x0 = xr & 0xffff, x1 = xr >> 16, y0 = yr & 0xffff, y1 = yr >> 16;
-      int bw = x1 - x0 + 1, total = bw * (y1 - y0 + 1);
-      for (int t = lane; t < total; t += 64) {
-        int dy = t / bw, dx = t - dy * bw;
-        int jy = y0 + dy, ix = x0 + dx;
-        float pz, w0, w1, w2;
-        if (mvr::face_test<float>(fs, px_tab[ix], py_tab[jy - jy_lo], persp, &pz, &w0, &w1, &w2)) {
-          unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
-          atomicMin(keys + (size_t)(jy_hi - jy) * W + (W - 1 - ix), key);
+    __syncthreads();
+#ifdef MVR_DIAG
+    unsigned long long tc2 = clock64();
+    t_small += tc2 - tc1;
+#endif
+    // ---- large faces (marked): one wave per face, lanes tile the bbox 8 x 8 ---------------------
+    for (int e = wave; e < n_list; e += MVR_WAVES) {
+      const int fm = list[e];
+      if (fm >= 0) continue;  // wave-uniform
+      const int f = fm & 0x7fffffff;
+#ifdef MVR_DIAG
+      ++n_large_tot;
+#endif
+      mvr::FaceSetup<float> fs = load_face(proj, faces, f, cull);
+      int x0, x1, y0, y1;
+      classify_face(fs, W, H, jy_lo, jy_hi, px_min, px_max, py_min, py_max, &x0, &x1, &y0, &y1);
+      const int lx = lane & 7, ly = lane >> 3;
+      for (int ty = y0; ty <= y1; ty += 8) {
+        const int jy = ty + ly;
+        for (int tx = x0; tx <= x1; tx += 8) {
+          const int ix = tx + lx;
+          float pz, w0, w1, w2;
+          if (jy <= y1 && ix <= x1 && mvr::face_test<float>(fs, px_tab[ix], py_tab[jy - jy_lo], persp, &pz, &w0, &w1, &w2)) {
+            unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
+            atomicMin(keys + (size_t)(jy_hi - jy) * W + (W - 1 - ix), key);
+          }
         }
       }
     }
     __syncthreads();
-    if (tid < 2) cnt[tid] = 0;
-    // (the next scan's first LDS list write happens after its ballots; the barrier above
-    //  already orders this round's list reads before them, and cnt is reset by the same
-    //  threads that next add to it only after the following barrier-free region — make it explicit)
-    __syncthreads();
+#ifdef MVR_DIAG
+    t_large += clock64() - tc2;
+    tc0 = clock64();
+#endif
+    if (!last) {
+      if (tid == 0) cnt[0] = 0;
+      __syncthreads();
+    }
   }
+  DIAG_STAMP(1);
+#ifdef MVR_DIAG
+  if (threadIdx.x == 0 && g_diag) {
+    g_diag[(size_t)blockIdx.x * 8 + 3] = t_scan; g_diag[(size_t)blockIdx.x * 8 + 4] = t_small;
+    g_diag[(size_t)blockIdx.x * 8 + 5] = t_large; g_diag[(size_t)blockIdx.x * 8 + 6] = n_small_tot;
+    g_diag[(size_t)blockIdx.x * 8 + 7] = n_large_tot * MVR_WAVES;
+  }
+#endif
 
   // ---- resolve + shade + store ------------------------------------------------------------
   float Rm[9], Tv[3];
@@ -427,18 +577,21 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
   const f3 light = {lp[0], lp[1], lp[2]};
   const mvr::Phong<float> ph = {a.ambient, a.diffuse, a.specular, a.shininess};
   const f3 objc = {a.obj[0], a.obj[1], a.obj[2]};
-  const float4 *vat = a.vattr + 2 * (size_t)vo;
-  const float *vcol = a.m.vert_colors ? a.m.vert_colors + 3 * (size_t)vo : nullptr;
+  const float4 *__restrict__ vat = a.vattr + 2 * (size_t)vo;
+  const float *__restrict__ vcol = a.m.vert_colors ? a.m.vert_colors + 3 * (size_t)vo : nullptr;
   const size_t HW = (size_t)H * W;
-  float *img = a.images + (size_t)n * 3 * HW + (size_t)r0 * W;
-  int32_t *p2f = a.p2f ? a.p2f + (size_t)n * HW + (size_t)r0 * W : nullptr;
-  for (int pix = tid; pix < rows * W; pix += MVR_BLOCK) {
+  float *__restrict__ img = a.images + (size_t)n * 3 * HW + (size_t)r0 * W;
+  int32_t *__restrict__ p2f = a.p2f ? a.p2f + (size_t)n * HW + (size_t)r0 * W : nullptr;
+  int row = tid / W, col = tid - row * W;
+  const int drow = MVR_BLOCK / W, dcol = MVR_BLOCK - drow * W;
+#pragma unroll 2
+  for (int pix = tid; pix < rows * W; pix += MVR_BLOCK, row += drow, col += dcol) {
+    if (col >= W) { col -= W; ++row; }
     unsigned long long key = keys[pix];
     float cr = a.bg[0], cg = a.bg[1], cb = a.bg[2];
     int face = -1;
     if (key != MVR_KEY_EMPTY) {
       face = (int)(unsigned)(key & 0xffffffffull);
-      int row = pix / W, col = pix - row * W;
       int i0 = faces[3 * face], i1 = faces[3 * face + 1], i2 = faces[3 * face + 2];
       mvr::FaceSetup<float> fs = mvr::face_setup<float>(ld3(proj + i0), ld3(proj + i1), ld3(proj + i2), cull);
       float w0, w1, w2, pz;
@@ -459,6 +612,7 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
     img[2 * HW + pix] = cb;
     if (p2f) p2f[pix] = face;
   }
+  DIAG_STAMP(2);
 }
 
 // ======================================================================================
@@ -751,17 +905,26 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_points_backward_finalize(const fl
 // ======================================================================================
 
 static int default_strip_rows(int H, int W) {
-  // keys (8 B/pixel) + tables + list must leave >= 2 workgroups per CU (160 KiB LDS)
-  int th = 16;
-  while (th > 1 && (size_t)th * W * 8 > 48 * 1024) th >>= 1;
+  // 8 B of depth key per pixel: <= 16 KiB of keys per workgroup keeps ~5+ workgroups resident per CU
+  // (160 KiB LDS) — the rasteriser hides its gather latency with occupancy
+  int th = 8;
+  while (th > 1 && (size_t)th * W * 8 > 16 * 1024) th >>= 1;
   if (th > H) th = H;
   return th;
+}
+
+// rows per row-bin of the (view, face) table: a multiple of the strip height with <= 254 bins per image
+static int bin_rows_for(int H, int TH) {
+  int n_strips = (H + TH - 1) / TH;
+  return TH * ((n_strips + 253) / 254);
 }
 
 struct MeshWs {
   long long *nacc;   // 3 * total_verts fixed-point normal sums
   float4 *vattr;     // 2 * total_verts
   float4 *proj;      // V * total_verts
+  unsigned short *bins;  // N * bin_stride
+  int bin_stride;
   float *partials;   // N * n_strips * 18
   size_t bytes;
 };
@@ -775,6 +938,8 @@ static MeshWs mesh_ws_layout(const mvr_mesh_batch *m, const mvr_mesh_params *p, 
   w.nacc = (long long *)((char *)base + off); off += align_up((size_t)3 * m->total_verts * sizeof(long long), 256);
   w.vattr = (float4 *)((char *)base + off); off += align_up((size_t)2 * m->total_verts * sizeof(float4), 256);
   w.proj = (float4 *)((char *)base + off); off += align_up((size_t)p->n_views * m->total_verts * sizeof(float4), 256);
+  w.bin_stride = (int)align_up((size_t)(m->max_faces > 0 ? m->max_faces : m->total_faces), 8);
+  w.bins = (unsigned short *)((char *)base + off); off += align_up(N * (size_t)w.bin_stride * sizeof(unsigned short), 256);
   w.partials = (float *)((char *)base + off); off += align_up(N * n_strips * MVR_NACC * sizeof(float), 256);
   w.bytes = off;
   return w;
@@ -794,11 +959,18 @@ static int check_mesh_args(const mvr_mesh_batch *m, const mvr_mesh_params *p) {
 
 extern "C" {
 
+#ifdef MVR_DIAG
+int mvr_diag_set_buffer(void *dev_ptr) {
+  unsigned long long *p = (unsigned long long *)dev_ptr;
+  return hip_check(hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &p, sizeof(p)), "mvr_diag_set_buffer");
+}
+#endif
+
 int mvr_version(void) { return 100; }
 
 int mvr_profile_begin(void) {
   for (int k = 0; k < PROF_KINDS; ++k) {
-    for (auto &p : g_prof_ev[k]) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto &p : g_prof_ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     g_prof_ev[k].clear();
   }
   g_prof_on = true;
@@ -813,7 +985,7 @@ int mvr_profile_end(double *total_ms, int32_t *launches) {
     for (auto &p : g_prof_ev[k]) {
       float ms = 0.f;
       if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { sum += ms; ++cnt; }
-      hipEventDestroy(p.first); hipEventDestroy(p.second);
+      (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
     }
     g_prof_ev[k].clear();
     if (total_ms) total_ms[k] = sum;
@@ -869,6 +1041,14 @@ size_t mvr_mesh_workspace_bytes(const mvr_mesh_batch *meshes, const mvr_mesh_par
 
 static int launch_vattr(const mvr_mesh_batch *m, const MeshWs &ws, float *normals_out, hipStream_t st) {
   MeshPtrs mp = {m->verts, m->faces, m->vert_off, m->face_off, m->vert_colors, m->n_meshes};
+  const int max_verts = m->max_verts > 0 ? m->max_verts : m->total_verts;
+  if (max_verts <= MVR_NRM_LDS_VERTS) {
+    size_t lds = (size_t)3 * max_verts * sizeof(unsigned long long);
+    if (lds > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute((const void *)k_vattr_mesh_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_vattr_mesh_lds, dim3(m->n_meshes), dim3(MVR_NRM_BLOCK), lds, st, mp, ws.vattr, normals_out);
+    return hip_check(hipGetLastError(), "k_vattr_mesh_lds");
+  }
   HIP_TRY(hipMemsetAsync(ws.nacc, 0, (size_t)3 * m->total_verts * sizeof(long long), st));
   hipLaunchKernelGGL(k_normals_accum, dim3((m->max_faces + MVR_BLOCK - 1) / MVR_BLOCK, m->n_meshes), dim3(MVR_BLOCK), 0, st, mp, ws.nacc);
   HIP_TRY(hipGetLastError());
@@ -910,7 +1090,14 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   hipLaunchKernelGGL(k_project_verts, dim3((max_verts + MVR_BLOCK - 1) / MVR_BLOCK, N), dim3(MVR_BLOCK), 0, st, mp, V, R, T, s, ws.proj);
   HIP_TRY(hipGetLastError());
 
+  const int G = bin_rows_for(H, TH);
+  const int max_faces = meshes->max_faces > 0 ? meshes->max_faces : meshes->total_faces;
+  hipLaunchKernelGGL(k_face_bins, dim3((max_faces + MVR_BLOCK - 1) / MVR_BLOCK, N), dim3(MVR_BLOCK), 0, st, mp, V, H, W, G,
+                     ws.bin_stride, (params->flags & MVR_CULL_BACKFACES) ? 1 : 0, ws.proj, ws.bins);
+  HIP_TRY(hipGetLastError());
+
   RasterArgs a;
+  a.bins = ws.bins; a.bin_rows = G; a.bin_stride = ws.bin_stride;
   a.m = mp; a.proj = ws.proj; a.vattr = ws.vattr; a.R = R; a.T = T; a.light = light_dir;
   a.images = images; a.p2f = pix_to_face;
   a.V = V; a.N = N; a.H = H; a.W = W; a.TH = TH; a.n_strips = n_strips;
@@ -918,7 +1105,7 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   a.n_light = params->n_light; a.flags = params->flags; a.s = s;
   a.ambient = params->ambient; a.diffuse = params->diffuse; a.specular = params->specular; a.shininess = params->shininess;
   for (int k = 0; k < 3; ++k) { a.obj[k] = params->obj_color[k]; a.bg[k] = params->bg_color[k]; }
-  size_t lds = (size_t)TH * W * 8 + (size_t)(W + TH) * 4 + (size_t)3 * MVR_CHUNK * 4 + 16;
+  size_t lds = (size_t)TH * W * 8 + (size_t)(W + TH) * 4 + (size_t)MVR_LIST_CAP * 4 + 16;
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_raster_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -31,6 +31,19 @@ MVR_HD double tsqrt(double x) { return sqrt(x); }
 MVR_HD float tabs(float x) { return fabsf(x); }
 MVR_HD double tabs(double x) { return fabs(x); }
 
+MVR_HD float tfma(float a, float b, float c) { return fmaf(a, b, c); }
+MVR_HD double tfma(double a, double b, double c) { return fma(a, b, c); }
+
+// a / b given y = RN(1/b) (the correctly rounded reciprocal, e.g. from one IEEE division shared by
+// several numerators): q = RN(a y); r = a - b q (exact, one FMA); RN(q + r y) = RN(a / b) — Markstein's
+// theorem; bit-identical to the IEEE quotient whenever no intermediate underflows (checked by brute force
+// in tests/test_hostmath.py).  3 VALU ops instead of the ~14 of a correctly rounded f32 division.
+template <typename T> MVR_HD T div_by(T a, T b, T y) {
+  T q = a * y;
+  T r = tfma(-b, q, a);
+  return tfma(r, y, q);
+}
+
 template <typename T> struct V3 { T x, y, z; };
 
 template <typename T> MVR_HD V3<T> cross(const V3<T> &a, const V3<T> &b) {
@@ -47,6 +60,17 @@ template <typename T> MVR_HD V3<T> normalize(const V3<T> &v, T eps, T *norm_out 
   if (norm_out) *norm_out = d;
   if (raw_norm) *raw_norm = n;
   return {v.x / d, v.y / d, v.z / d};
+}
+
+// Shading-only variant: one reciprocal shared by the three components (div_by keeps it equal to the
+// three IEEE divisions of F.normalize).
+template <typename T> MVR_HD V3<T> normalize_shared(const V3<T> &v, T eps, T *norm_out = nullptr, T *raw_norm = nullptr) {
+  T n = tsqrt((v.x * v.x + v.y * v.y) + v.z * v.z);
+  T d = tmax(n, eps);
+  if (norm_out) *norm_out = d;
+  if (raw_norm) *raw_norm = n;
+  T y = (T)1 / d;
+  return {div_by(v.x, d, y), div_by(v.y, d, y), div_by(v.z, d, y)};
 }
 
 // gradient of normalize: out = v/d, d = max(n, eps).  n > eps: (g - out (out.g))/d ; else g/d.
@@ -224,6 +248,7 @@ template <typename T> struct FaceSetup {
   V3<T> v0, v1, v2;            // NDC x, y ; view z
   T xmin, xmax, ymin, ymax;
   T area;                      // edge(v2; v0, v1) + kEps  (barycentric denominator)
+  T inv_area;                  // RN(1 / area): shared by the three barycentric divisions (div_by)
   bool drawable;               // passes the per-face culls
 };
 
@@ -239,22 +264,31 @@ template <typename T> MVR_HD FaceSetup<T> face_setup(const V3<T> &v0, const V3<T
   bool z_invalid = zmin < (T)kEps;
   fs.drawable = !(zmax < (T)0 || (cull_backfaces && back_face) || z_invalid || zero_area);
   fs.area = edge_fn(v2.x, v2.y, v0.x, v0.y, v1.x, v1.y) + (T)kEps;
+  fs.inv_area = (T)1 / fs.area;
   return fs;
 }
 
-// Barycentrics (optionally perspective-corrected) and interpolated z of pixel centre (px,py);
-// no inside test.
-template <typename T> MVR_HD void face_bary(const FaceSetup<T> &fs, T px, T py, bool persp, T *w0, T *w1, T *w2, T *pz) {
-  T a0 = edge_fn(px, py, fs.v1.x, fs.v1.y, fs.v2.x, fs.v2.y) / fs.area;
-  T a1 = edge_fn(px, py, fs.v2.x, fs.v2.y, fs.v0.x, fs.v0.y) / fs.area;
-  T a2 = edge_fn(px, py, fs.v0.x, fs.v0.y, fs.v1.x, fs.v1.y) / fs.area;
+// Barycentrics (optionally perspective-corrected) and interpolated z of pixel centre (px,py) from the
+// three edge values; no inside test.  Every quotient equals the IEEE division of the oracle (div_by).
+template <typename T> MVR_HD void bary_from_edges(const FaceSetup<T> &fs, T e0, T e1, T e2, bool persp, T *w0, T *w1, T *w2, T *pz) {
+  T a0 = div_by(e0, fs.area, fs.inv_area);
+  T a1 = div_by(e1, fs.area, fs.inv_area);
+  T a2 = div_by(e2, fs.area, fs.inv_area);
   if (persp) {
     T t0 = (a0 * fs.v1.z) * fs.v2.z, t1 = (fs.v0.z * a1) * fs.v2.z, t2 = (fs.v0.z * fs.v1.z) * a2;
     T den = tmax((t0 + t1) + t2, (T)kEps);
-    a0 = t0 / den; a1 = t1 / den; a2 = t2 / den;
+    T yd = (T)1 / den;
+    a0 = div_by(t0, den, yd); a1 = div_by(t1, den, yd); a2 = div_by(t2, den, yd);
   }
   *w0 = a0; *w1 = a1; *w2 = a2;
   *pz = (a0 * fs.v0.z + a1 * fs.v1.z) + a2 * fs.v2.z;
+}
+
+template <typename T> MVR_HD void face_bary(const FaceSetup<T> &fs, T px, T py, bool persp, T *w0, T *w1, T *w2, T *pz) {
+  T e0 = edge_fn(px, py, fs.v1.x, fs.v1.y, fs.v2.x, fs.v2.y);
+  T e1 = edge_fn(px, py, fs.v2.x, fs.v2.y, fs.v0.x, fs.v0.y);
+  T e2 = edge_fn(px, py, fs.v0.x, fs.v0.y, fs.v1.x, fs.v1.y);
+  bary_from_edges(fs, e0, e1, e2, persp, w0, w1, w2, pz);
 }
 
 // CheckPixelInsideFace with blur_radius = 0: true iff the pixel centre is strictly inside.
@@ -267,7 +301,7 @@ template <typename T> MVR_HD bool face_test(const FaceSetup<T> &fs, T px, T py, 
   bool pos = fs.area > (T)0;
   bool maybe = pos ? (e0 > (T)0 && e1 > (T)0 && e2 > (T)0) : (e0 < (T)0 && e1 < (T)0 && e2 < (T)0);
   if (!maybe) return false;
-  face_bary(fs, px, py, persp, w0, w1, w2, pz);
+  bary_from_edges(fs, e0, e1, e2, persp, w0, w1, w2, pz);
   if (*pz < (T)0) return false;
   return *w0 > (T)0 && *w1 > (T)0 && *w2 > (T)0;
 }
@@ -290,13 +324,13 @@ template <typename T> MVR_HD V3<T> phong_pixel(T w0, T w1, T w2, const V3<T> &X0
   V3<T> p = {(w0 * X0.x + w1 * X1.x) + w2 * X2.x, (w0 * X0.y + w1 * X1.y) + w2 * X2.y, (w0 * X0.z + w1 * X1.z) + w2 * X2.z};
   V3<T> n = {(w0 * N0.x + w1 * N1.x) + w2 * N2.x, (w0 * N0.y + w1 * N1.y) + w2 * N2.y, (w0 * N0.z + w1 * N1.z) + w2 * N2.z};
   V3<T> tex = {(w0 * c0.x + w1 * c1.x) + w2 * c2.x, (w0 * c0.y + w1 * c1.y) + w2 * c2.y, (w0 * c0.z + w1 * c1.z) + w2 * c2.z};
-  V3<T> nh = normalize(n, (T)kNormalizeEps);
-  V3<T> lh = normalize(l, (T)kNormalizeEps);
+  V3<T> nh = normalize_shared(n, (T)kNormalizeEps);
+  V3<T> lh = normalize_shared(l, (T)kNormalizeEps);
   T cosang = dot(nh, lh);
   T diff = cosang > (T)0 ? cosang : (T)0;
   T mask = cosang > (T)0 ? (T)1 : (T)0;
   V3<T> view = {cc.x - p.x, cc.y - p.y, cc.z - p.z};
-  V3<T> vh = normalize(view, (T)kNormalizeEps);
+  V3<T> vh = normalize_shared(view, (T)kNormalizeEps);
   V3<T> refl = {-lh.x + (T)2 * (cosang * nh.x), -lh.y + (T)2 * (cosang * nh.y), -lh.z + (T)2 * (cosang * nh.z)};
   T dvr = dot(vh, refl);
   T alpha = (dvr > (T)0 ? dvr : (T)0) * mask;
@@ -341,12 +375,12 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
   V3<T> n = {(w0 * N0.x + w1 * N1.x) + w2 * N2.x, (w0 * N0.y + w1 * N1.y) + w2 * N2.y, (w0 * N0.z + w1 * N1.z) + w2 * N2.z};
   V3<T> tex = {(w0 * c0.x + w1 * c1.x) + w2 * c2.x, (w0 * c0.y + w1 * c1.y) + w2 * c2.y, (w0 * c0.z + w1 * c1.z) + w2 * c2.z};
   T dn, rn, dl, rl, dv, rv;
-  V3<T> nh = normalize(n, (T)kNormalizeEps, &dn, &rn);
-  V3<T> lh = normalize(cam.l, (T)kNormalizeEps, &dl, &rl);
+  V3<T> nh = normalize_shared(n, (T)kNormalizeEps, &dn, &rn);
+  V3<T> lh = normalize_shared(cam.l, (T)kNormalizeEps, &dl, &rl);
   T cosang = dot(nh, lh);
   bool lit = cosang > (T)0;
   V3<T> view = {cam.cc.x - p.x, cam.cc.y - p.y, cam.cc.z - p.z};
-  V3<T> vh = normalize(view, (T)kNormalizeEps, &dv, &rv);
+  V3<T> vh = normalize_shared(view, (T)kNormalizeEps, &dv, &rv);
   V3<T> refl = {-lh.x + (T)2 * (cosang * nh.x), -lh.y + (T)2 * (cosang * nh.y), -lh.z + (T)2 * (cosang * nh.z)};
   T dvr = dot(vh, refl);
   bool spec_on = lit && dvr > (T)0;

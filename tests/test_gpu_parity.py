@@ -34,6 +34,28 @@ def _mesh_batch(specs):
     return vl, fl
 
 
+def _well_conditioned_pixels(vl, fl, p2f, V):
+    """Pixels whose winning face has three WELL-CONDITIONED vertex normals.  Where the area-weighted face
+    normals of a vertex cancel (double-sided CAD quads: |sum n_f| << sum |n_f|) the normalised sum is
+    rounding noise in ANY implementation (it depends on summation order; PyTorch3D's own CPU index_add and
+    GPU atomics disagree there), so image parity is only asserted on the rest; coverage parity on all."""
+    mask = np.ones(p2f.shape, bool)
+    for b, (v, f) in enumerate(zip(vl, fl)):
+        v64 = v.astype(np.float64)
+        nf = np.cross(v64[f[:, 2]] - v64[f[:, 1]], v64[f[:, 0]] - v64[f[:, 1]])
+        s, a = np.zeros_like(v64), np.zeros(len(v))
+        for k in range(3):
+            np.add.at(s, f[:, k], nf)
+            np.add.at(a, f[:, k], np.linalg.norm(nf, axis=1))
+        well_v = np.linalg.norm(s, axis=1) > 1e-3 * np.maximum(a, 1e-30)
+        well_f = well_v[f].all(1)
+        sl = p2f[b * V:(b + 1) * V]
+        m = np.ones(sl.shape, bool)
+        m[sl >= 0] = well_f[sl[sl >= 0]]
+        mask[b * V:(b + 1) * V] = m
+    return mask
+
+
 def _views(B, V, seed, jitter=True):
     az, el, di = syn.spherical_views(V)
     az, el, di = np.tile(az, (B, 1)), np.tile(el, (B, 1)), np.tile(di, (B, 1))
@@ -70,9 +92,14 @@ def test_vertex_normals(oracle):
     vl, fl = _mesh_batch([("S", 0), ("M", 1), ("soup", 2)])
     packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
     got = F.vertex_normals(packed).cpu().numpy()
+    got2 = F.vertex_normals(packed).cpu().numpy()
+    assert np.array_equal(got, got2), "fixed-point accumulation must be bit-reproducible"
     want = np.concatenate([oracle.vertex_normals(v, f) for v, f in zip(vl, fl)], 0)
-    # float atomics: accumulation order differs from the sequential index_add
-    assert np.abs(got - want).max() < 2e-5
+    # summation order differs from the sequential index_add (exact fixed-point sum vs float adds);
+    # the CAD soup's normals cancel to rounding noise and are excluded (see _well_conditioned_pixels)
+    n_ok = len(vl[0]) + len(vl[1])
+    assert np.abs(got[:n_ok] - want[:n_ok]).max() < 2e-5
+    assert np.isfinite(got).all() and np.abs(np.linalg.norm(got[:n_ok], axis=1) - 1).max() < 1e-5
 
 
 @pytest.mark.parametrize("size,specs,V,persp,cull,light,strip", [
@@ -104,11 +131,14 @@ def test_mesh_forward_parity(oracle, size, specs, V, persp, cull, light, strip):
     torch.cuda.synchronize()
     p2f, img = p2f.cpu().numpy(), img.cpu().numpy()
     n_diff = int((p2f != want["pix_to_face"]).sum())
-    err = float(np.abs(img - want["images"]).max())
-    print("coverage mismatches: %d  max|d|: %.3g  covered: %.3f" % (n_diff, err, (p2f >= 0).mean()))
+    well = _well_conditioned_pixels(vl, fl, want["pix_to_face"], V)
+    diff = np.abs(img - want["images"]).reshape(B * V, 3, size, size).max(1)
+    err = float(diff[well].max())
+    print("coverage mismatches: %d  max|d|: %.3g  covered: %.3f  ill-conditioned px: %d" % (
+        n_diff, err, (p2f >= 0).mean(), int((~well).sum())))
     assert n_diff == 0, "pixel->face map differs from the oracle at %d pixels" % n_diff
     assert err <= TOL_PIXEL
-    assert img.shape == (B, V, 3, size, size)
+    assert img.shape == (B, V, 3, size, size) and np.isfinite(img).all()
 
 
 def test_mesh_custom_vertex_colors(oracle):
@@ -305,9 +335,10 @@ def test_rotation_remedy_device_statistics():
     C = -torch.bmm(R, T[:, :, None])[:, :, 0].cpu().numpy().astype(np.float64)
     elev_used = np.degrees(np.arcsin(C[:, 1] / 2.2))
     azim_used = np.degrees(np.arctan2(C[:, 0], C[:, 2])) % 360
-    if int(status[0]) == 1:
-        assert 0 <= azim_used.min() and azim_used.max() < 180.01
-        assert abs(azim_used.mean() - 90) < 10 and abs(np.delete(elev_used, 0).mean() - 45) < 5
+    if int(status[0]) == 1:  # view 0 started at elev 89.9999 and may pass the pole: judge the others
+        a, e = np.delete(azim_used, 0), np.delete(elev_used, 0)
+        assert 0 <= a.min() and a.max() < 180.01 and 0 <= e.min() and e.max() < 90.01
+        assert abs(a.mean() - 90) < 10 and abs(e.mean() - 45) < 5
     # a different seed gives a different draw; the same seed reproduces it
     R2, _, _ = F._LookAt.apply(az, el, di, 20, 1234)
     R3, _, _ = F._LookAt.apply(az, el, di, 20, 99)
