@@ -34,8 +34,9 @@ typedef V3<float> f3;
 
 #define MVR_BLOCK 256
 #define MVR_WAVES (MVR_BLOCK / 64)
-#define MVR_LIST_CAP 3072       // LDS face list (4 B entries): flushed before a worst-case scan round (2048) could overflow it
-#define MVR_SMALL_MAX 64        // bbox pixels (within the strip) up to which a face is "small"
+#define MVR_SCAN_PER_LANE 4     // faces per lane per scan round (one 8-byte vector of 2-byte row-bin ranges)
+#define MVR_LIST_CAP 1536       // LDS face list (4 B entries): flushed before a worst-case scan round (1024) could overflow it
+#define MVR_BATCH 256           // faces set up / rasterised per batch (one per lane in the setup phase)
 #define MVR_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define MVR_NACC 18
 
@@ -403,20 +404,16 @@ __device__ __forceinline__ void decode_block(int bid, int n_strips, int views_pe
   *strip = j % n_strips;
 }
 
-// Face classification by the number of candidate pixels (bbox ∩ strip): entries are appended to an
-// LDS list — small faces from the front, large faces from the back.
-__device__ __forceinline__ int classify_face(const mvr::FaceSetup<float> &fs, int W, int H, int jy_lo, int jy_hi,
-                                             float px_min, float px_max, float py_min, float py_max,
-                                             int *x0, int *x1, int *y0, int *y1) {
-  // a pixel passes the bbox test iff xmin <= px <= xmax and ymin <= py <= ymax
-  bool hit = fs.drawable && fs.ymax >= py_min && fs.ymin <= py_max && fs.xmax >= px_min && fs.xmin <= px_max;
-  if (!hit) return 0;
+// Exact-conservative candidate pixel range of a face inside the strip; returns the number of candidates
+// (0: the face cannot touch a pixel centre of this strip).
+__device__ __forceinline__ int face_range(const mvr::FaceSetup<float> &fs, int W, int H, int jy_lo, int jy_hi,
+                                          int *x0, int *x1, int *y0, int *y1) {
+  if (!fs.drawable) return 0;
   ndc_range(fs.xmin, fs.xmax, W, x0, x1);
   ndc_range(fs.ymin, fs.ymax, H, y0, y1);
   *y0 = max(*y0, jy_lo); *y1 = min(*y1, jy_hi);
-  if (*x0 > *x1 || *y0 > *y1) return 0;
-  int count = (*x1 - *x0 + 1) * (*y1 - *y0 + 1);
-  return count <= MVR_SMALL_MAX ? 1 : 2;
+  if (!(*x0 <= *x1 && *y0 <= *y1)) return 0;   // also rejects NaN bounds (ranges come out inverted)
+  return (*x1 - *x0 + 1) * (*y1 - *y0 + 1);
 }
 
 __device__ __forceinline__ mvr::FaceSetup<float> load_face(const float4 *__restrict__ proj, const int32_t *__restrict__ faces,
@@ -425,14 +422,35 @@ __device__ __forceinline__ mvr::FaceSetup<float> load_face(const float4 *__restr
   return mvr::face_setup<float>(ld3(proj + i0), ld3(proj + i1), ld3(proj + i2), cull);
 }
 
+// LDS record of one face of the current batch: everything the per-pixel test needs.
+struct FaceCoef { float4 a, b, c; };  // a = v0.xyz v1.x | b = v1.yz v2.xy | c = v2.z area inv_area face(bits)
+
+__device__ __forceinline__ void unpack_face(const FaceCoef &q, mvr::FaceSetup<float> &fs, int &f) {
+  fs.v0 = {q.a.x, q.a.y, q.a.z}; fs.v1 = {q.a.w, q.b.x, q.b.y}; fs.v2 = {q.b.z, q.b.w, q.c.x};
+  fs.area = q.c.y; fs.inv_area = q.c.z; f = __float_as_int(q.c.w);
+  fs.xmin = mvr::tmin(mvr::tmin(fs.v0.x, fs.v1.x), fs.v2.x); fs.xmax = mvr::tmax(mvr::tmax(fs.v0.x, fs.v1.x), fs.v2.x);
+  fs.ymin = mvr::tmin(mvr::tmin(fs.v0.y, fs.v1.y), fs.v2.y); fs.ymax = mvr::tmax(mvr::tmax(fs.v0.y, fs.v1.y), fs.v2.y);
+  fs.drawable = true;
+}
+
+// One workgroup per (view, strip of TH image rows).
+//   scan     : 2-byte row-bin ranges of the view's faces (k_face_bins) -> LDS list of faces touching the strip
+//   setup    : one lane per listed face: gather its 3 projected vertices, exact candidate range, coefficient
+//              record -> LDS; workgroup prefix sum of the candidate counts
+//   raster   : the candidate (face, pixel) pairs of the batch are split EVENLY over the 256 lanes (each lane
+//              takes a contiguous run of the concatenated per-face pixel lists, located by a binary search of
+//              the prefix sums) -> no lane waits for another lane's big triangle; any face size is handled by
+//              the same loop.  Depth resolve: 64-bit LDS atomicMin on (float_bits(z) << 32 | face).
+//   shade    : every pixel of the strip: winner -> barycentrics -> Phong + hard blend -> planar store.
 __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int W = a.W, H = a.H, TH = a.TH;
-  unsigned long long *keys = (unsigned long long *)smem;                 // TH * W
-  float *px_tab = (float *)(keys + (size_t)TH * W);                      // W   (index = NDC index i)
-  float *py_tab = px_tab + W;                                            // TH  (index = jy - jy_lo)
-  int *list = (int *)(py_tab + TH);                                      // MVR_LIST_CAP face indices (bit 31: large)
-  int *cnt = list + MVR_LIST_CAP;                                        // [0] entries
+  unsigned long long *keys = (unsigned long long *)smem;                       // TH * W
+  FaceCoef *coef = (FaceCoef *)(keys + (size_t)TH * W);                        // MVR_BATCH
+  int2 *rng = (int2 *)(coef + MVR_BATCH);                                      // MVR_BATCH: x0|x1<<16 , y0|y1<<16
+  int *cum = (int *)(rng + MVR_BATCH);                                         // MVR_BATCH + 1 exclusive prefix sums
+  int *list = cum + (MVR_BATCH + 1);                                           // MVR_LIST_CAP face indices
+  int *cnt = list + MVR_LIST_CAP;                                              // [0] list entries, [1..4] wave totals
 
   int n, strip;
   decode_block(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
@@ -450,29 +468,27 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
   const unsigned g_lo = (unsigned)(r0 / a.bin_rows), g_hi = (unsigned)((r0 + rows - 1) / a.bin_rows);
   const bool persp = (a.flags & MVR_PERSPECTIVE_CORRECT) != 0;
   const bool cull = (a.flags & MVR_CULL_BACKFACES) != 0;
+  // pixel centre of NDC index i: -1 + (2 i + 1)/S, the division done as div_by with RN(1/S): bit-identical
+  const float fW = (float)W, fH = (float)H, invW = 1.0f / fW, invH = 1.0f / fH;
 
   for (int i = tid; i < rows * W; i += MVR_BLOCK) keys[i] = MVR_KEY_EMPTY;
-  for (int i = tid; i < W; i += MVR_BLOCK) px_tab[i] = mvr::pix_to_ndc<float>(i, W);
-  for (int i = tid; i < rows; i += MVR_BLOCK) py_tab[i] = mvr::pix_to_ndc<float>(jy_lo + i, H);
   if (tid == 0) cnt[0] = 0;
   __syncthreads();
-  const float py_min = py_tab[0], py_max = py_tab[rows - 1];
-  const float px_min = px_tab[0], px_max = px_tab[W - 1];
 
   DIAG_STAMP(0);
 #ifdef MVR_DIAG
   unsigned long long t_scan = 0, t_small = 0, t_large = 0, n_small_tot = 0, n_large_tot = 0;
   unsigned long long tc0 = clock64();
 #endif
-  for (int base = 0; base < nf; base += MVR_BLOCK * 8) {
-    // ---- scan: 8 faces (one 16-byte vector of row-bin ranges) per lane; compact hits into the LDS list ----
-    const int f0 = base + tid * 8;
+  for (int base = 0; base < nf; base += MVR_BLOCK * MVR_SCAN_PER_LANE) {
+    // ---- scan: 4 faces (one 8-byte vector of row-bin ranges) per lane; compact hits into the LDS list ----
+    const int f0 = base + tid * MVR_SCAN_PER_LANE;
     unsigned hit = 0;
     if (f0 < nf) {
-      const uint4 q = *reinterpret_cast<const uint4 *>(bins + f0);
-      const unsigned w[4] = {q.x, q.y, q.z, q.w};
+      const uint2 q = *reinterpret_cast<const uint2 *>(bins + f0);
+      const unsigned w[2] = {q.x, q.y};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < MVR_SCAN_PER_LANE; ++k) {
         unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
         unsigned e0 = e & 0xffu, e1 = e >> 8;
         bool h = (e != MVR_BIN_NONE) && e0 <= g_hi && e1 >= g_lo && (f0 + k) < nf;
@@ -480,7 +496,7 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
       }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < MVR_SCAN_PER_LANE; ++k) {
       const bool h = (hit >> k) & 1u;
       unsigned long long mh = __ballot(h);
       if (mh) {  // wave-uniform
@@ -492,64 +508,107 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
     }
     __syncthreads();
     const int n_list = cnt[0];
-    const bool last = base + MVR_BLOCK * 8 >= nf;
-    if (!last && n_list + MVR_BLOCK * 8 <= MVR_LIST_CAP) continue;  // room for another worst-case scan round
+    const bool last = base + MVR_BLOCK * MVR_SCAN_PER_LANE >= nf;
+    if (!last && n_list + MVR_BLOCK * MVR_SCAN_PER_LANE <= MVR_LIST_CAP) continue;  // room for a worst-case scan round
 #ifdef MVR_DIAG
     unsigned long long tc1 = clock64();
     t_scan += tc1 - tc0; n_small_tot += n_list;
 #endif
-    // ---- small faces: one lane per face; faces with many candidate pixels are only marked ------
-    for (int e = tid; e < n_list; e += MVR_BLOCK) {
-      const int f = list[e];
-      mvr::FaceSetup<float> fs = load_face(proj, faces, f, cull);
-      int x0, x1, y0, y1;
-      const int kind = classify_face(fs, W, H, jy_lo, jy_hi, px_min, px_max, py_min, py_max, &x0, &x1, &y0, &y1);
-      if (kind == 2) { list[e] = f | (int)0x80000000; continue; }
-      if (kind == 0) continue;
-      for (int jy = y0; jy <= y1; ++jy) {
-        const float py = py_tab[jy - jy_lo];
-        unsigned long long *krow = keys + (size_t)(jy_hi - jy) * W + (W - 1);
-        for (int ix = x0; ix <= x1; ++ix) {
-          float pz, w0, w1, w2;
-          if (mvr::face_test<float>(fs, px_tab[ix], py, persp, &pz, &w0, &w1, &w2)) {
-            unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
-            atomicMin(krow - ix, key);
-          }
-        }
+    for (int b0 = 0; b0 < n_list; b0 += MVR_BATCH) {
+      const int nb = min(MVR_BATCH, n_list - b0);
+#ifdef MVR_DIAG
+      unsigned long long ts0 = clock64();
+#endif
+      // ---- setup: one lane per face of the batch ------------------------------------------------
+      int my_cnt = 0;
+      if (tid < nb) {
+        const int f = list[b0 + tid];
+        const mvr::FaceSetup<float> fs = load_face(proj, faces, f, cull);
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        my_cnt = face_range(fs, W, H, jy_lo, jy_hi, &x0, &x1, &y0, &y1);
+        FaceCoef q;
+        q.a = make_float4(fs.v0.x, fs.v0.y, fs.v0.z, fs.v1.x);
+        q.b = make_float4(fs.v1.y, fs.v1.z, fs.v2.x, fs.v2.y);
+        q.c = make_float4(fs.v2.z, fs.area, fs.inv_area, __int_as_float(f));
+        coef[tid] = q;
+        rng[tid] = make_int2(x0 | (x1 << 16), y0 | (y1 << 16));
       }
-    }
-    __syncthreads();
+      // workgroup exclusive prefix sum of the candidate counts
+      int incl = my_cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      if (lane == 63) cnt[1 + wave] = incl;
+      __syncthreads();
+      int wave_off = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < MVR_WAVES; ++w) {
+        int t = cnt[1 + w];
+        if (w < wave) wave_off += t;
+        total += t;
+      }
+      cum[tid] = wave_off + incl - my_cnt;
+      if (tid == 0) cum[MVR_BATCH] = total;
+      __syncthreads();
 #ifdef MVR_DIAG
-    unsigned long long tc2 = clock64();
-    t_small += tc2 - tc1;
+      unsigned long long ts1 = clock64();
+      t_small += ts1 - ts0; n_large_tot += total;
 #endif
-    // ---- large faces (marked): one wave per face, lanes tile the bbox 8 x 8 ---------------------
-    for (int e = wave; e < n_list; e += MVR_WAVES) {
-      const int fm = list[e];
-      if (fm >= 0) continue;  // wave-uniform
-      const int f = fm & 0x7fffffff;
-#ifdef MVR_DIAG
-      ++n_large_tot;
-#endif
-      mvr::FaceSetup<float> fs = load_face(proj, faces, f, cull);
-      int x0, x1, y0, y1;
-      classify_face(fs, W, H, jy_lo, jy_hi, px_min, px_max, py_min, py_max, &x0, &x1, &y0, &y1);
-      const int lx = lane & 7, ly = lane >> 3;
-      for (int ty = y0; ty <= y1; ty += 8) {
-        const int jy = ty + ly;
-        for (int tx = x0; tx <= x1; tx += 8) {
-          const int ix = tx + lx;
+      // ---- raster: balanced split of the batch's `total` (face, pixel) candidates over 256 lanes -------
+      const int quota = (total + MVR_BLOCK - 1) / MVR_BLOCK;
+      const int p0 = tid * quota;
+      int rem = min(quota, total - p0);
+      if (rem > 0) {
+        // e = last entry with cum[e] <= p0  (upper_bound - 1); entries with zero candidates are skipped by it
+        int lo = 0, hi = MVR_BATCH;  // invariant: cum[lo] <= p0 < cum[hi]
+        while (hi - lo > 1) {
+          int mid = (lo + hi) >> 1;
+          if (cum[mid] <= p0) lo = mid; else hi = mid;
+        }
+        int e = lo;
+        mvr::FaceSetup<float> fs;
+        int f, x0, x1, y0, y1, ix, jy, left;
+        {
+          unpack_face(coef[e], fs, f);
+          const int2 r = rng[e];
+          x0 = r.x & 0xffff; x1 = r.x >> 16; y0 = r.y & 0xffff; y1 = r.y >> 16;
+          const int bw = x1 - x0 + 1;
+          const int o = p0 - cum[e];
+          const int dy = o / bw;
+          jy = y0 + dy; ix = x0 + (o - dy * bw);
+          left = bw * (y1 - y0 + 1) - o;
+        }
+        float py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);
+        while (true) {
+          const float px = -1.0f + mvr::div_by(2.0f * (float)ix + 1.0f, fW, invW);
           float pz, w0, w1, w2;
-          if (jy <= y1 && ix <= x1 && mvr::face_test<float>(fs, px_tab[ix], py_tab[jy - jy_lo], persp, &pz, &w0, &w1, &w2)) {
+          if (mvr::face_test<float>(fs, px, py, persp, &pz, &w0, &w1, &w2)) {
             unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
             atomicMin(keys + (size_t)(jy_hi - jy) * W + (W - 1 - ix), key);
           }
+          if (--rem == 0) break;
+          if (--left == 0) {
+            do { ++e; } while (cum[e + 1] == cum[e]);   // next face with candidates (exists: rem > 0)
+            unpack_face(coef[e], fs, f);
+            const int2 r = rng[e];
+            x0 = r.x & 0xffff; x1 = r.x >> 16; y0 = r.y & 0xffff; y1 = r.y >> 16;
+            left = (x1 - x0 + 1) * (y1 - y0 + 1);
+            ix = x0; jy = y0;
+            py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);
+          } else if (++ix > x1) {
+            ix = x0; ++jy;
+            py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);
+          }
         }
       }
-    }
-    __syncthreads();
+      __syncthreads();   // coef / rng / cum are rewritten by the next batch; keys are complete for this one
 #ifdef MVR_DIAG
-    t_large += clock64() - tc2;
+      t_large += clock64() - ts1;
+#endif
+    }
+#ifdef MVR_DIAG
     tc0 = clock64();
 #endif
     if (!last) {
@@ -562,7 +621,7 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
   if (threadIdx.x == 0 && g_diag) {
     g_diag[(size_t)blockIdx.x * 8 + 3] = t_scan; g_diag[(size_t)blockIdx.x * 8 + 4] = t_small;
     g_diag[(size_t)blockIdx.x * 8 + 5] = t_large; g_diag[(size_t)blockIdx.x * 8 + 6] = n_small_tot;
-    g_diag[(size_t)blockIdx.x * 8 + 7] = n_large_tot * MVR_WAVES;
+    g_diag[(size_t)blockIdx.x * 8 + 7] = n_large_tot;
   }
 #endif
 
@@ -595,7 +654,8 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
       int i0 = faces[3 * face], i1 = faces[3 * face + 1], i2 = faces[3 * face + 2];
       mvr::FaceSetup<float> fs = mvr::face_setup<float>(ld3(proj + i0), ld3(proj + i1), ld3(proj + i2), cull);
       float w0, w1, w2, pz;
-      mvr::face_bary<float>(fs, px_tab[W - 1 - col], py_tab[jy_hi - row - jy_lo], persp, &w0, &w1, &w2, &pz);
+      mvr::face_bary<float>(fs, -1.0f + mvr::div_by(2.0f * (float)(W - 1 - col) + 1.0f, fW, invW),
+                            -1.0f + mvr::div_by(2.0f * (float)(jy_hi - row) + 1.0f, fH, invH), persp, &w0, &w1, &w2, &pz);
       f3 c0 = objc, c1 = objc, c2 = objc;
       if (vcol) {
         c0 = {vcol[3 * i0], vcol[3 * i0 + 1], vcol[3 * i0 + 2]};
@@ -938,7 +998,7 @@ static MeshWs mesh_ws_layout(const mvr_mesh_batch *m, const mvr_mesh_params *p, 
   w.nacc = (long long *)((char *)base + off); off += align_up((size_t)3 * m->total_verts * sizeof(long long), 256);
   w.vattr = (float4 *)((char *)base + off); off += align_up((size_t)2 * m->total_verts * sizeof(float4), 256);
   w.proj = (float4 *)((char *)base + off); off += align_up((size_t)p->n_views * m->total_verts * sizeof(float4), 256);
-  w.bin_stride = (int)align_up((size_t)(m->max_faces > 0 ? m->max_faces : m->total_faces), 8);
+  w.bin_stride = (int)align_up((size_t)(m->max_faces > 0 ? m->max_faces : m->total_faces), 8);  // 8-byte vector reads need a multiple of 4
   w.bins = (unsigned short *)((char *)base + off); off += align_up(N * (size_t)w.bin_stride * sizeof(unsigned short), 256);
   w.partials = (float *)((char *)base + off); off += align_up(N * n_strips * MVR_NACC * sizeof(float), 256);
   w.bytes = off;
@@ -1105,7 +1165,8 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   a.n_light = params->n_light; a.flags = params->flags; a.s = s;
   a.ambient = params->ambient; a.diffuse = params->diffuse; a.specular = params->specular; a.shininess = params->shininess;
   for (int k = 0; k < 3; ++k) { a.obj[k] = params->obj_color[k]; a.bg[k] = params->bg_color[k]; }
-  size_t lds = (size_t)TH * W * 8 + (size_t)(W + TH) * 4 + (size_t)MVR_LIST_CAP * 4 + 16;
+  size_t lds = (size_t)TH * W * 8 + (size_t)MVR_BATCH * (sizeof(FaceCoef) + sizeof(int2)) + (size_t)(MVR_BATCH + 1) * 4 +
+               (size_t)MVR_LIST_CAP * 4 + 8 * 4;
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_raster_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
