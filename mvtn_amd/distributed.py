@@ -29,13 +29,15 @@ class _AllGatherViews(torch.autograd.Function):
         rank = dist.get_rank(group)
         ctx.counts, ctx.group, ctx.rank = counts, group, rank
         local = local.contiguous()
+        mx = max(counts)
+        if local.shape[0] != mx:  # uneven shards: pad to the largest so ONE fixed-size all-gather serves every backend
+            pad = local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))
+            local = torch.cat([local, pad], 0)
+        out = local.new_empty((world * mx,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, local, group=group)
         if len(set(counts)) == 1:
-            out = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))
-            dist.all_gather_into_tensor(out, local, group=group)
             return out
-        parts = [local.new_empty((c,) + tuple(local.shape[1:])) for c in counts]
-        dist.all_gather(parts, local, group=group)
-        return torch.cat(parts, 0)
+        return torch.cat([out[r * mx:r * mx + c] for r, c in enumerate(counts)], 0)
 
     @staticmethod
     def backward(ctx, g):
@@ -43,12 +45,15 @@ class _AllGatherViews(torch.autograd.Function):
         g = g.contiguous()
         if len(set(counts)) == 1:
             out = g.new_empty((counts[0],) + tuple(g.shape[1:]))
-            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=group)
-            return out, None, None
-        parts = [p.contiguous() for p in torch.split(g, counts, 0)]
-        out = torch.empty_like(parts[rank])
-        dist.reduce_scatter(out, parts, op=dist.ReduceOp.SUM, group=group)
-        return out, None, None
+            try:
+                dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=group)
+                return out, None, None
+            except RuntimeError:  # backend without reduce-scatter (gloo): all-reduce + slice
+                pass
+        g = g.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        lo = sum(counts[:rank])
+        return g[lo:lo + counts[rank]].contiguous(), None, None
 
 
 def all_gather_views(local_images, counts=None, group=None):

@@ -1,0 +1,192 @@
+"""CPU (-m "not gpu"): host-side logic of the product against the golden vectors captured from the
+reference's own caller-side code (tests/golden/caller_side.json), the C-ABI surface, and the packing."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from mvtn_amd import synthetic as syn
+from mvtn_amd.helpers import batch_tensor, check_valid_rotation_matrix, flatten_views, torch_color, unbatch_tensor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_unit_spherical_grid_matches_reference(golden):
+    for n, g in golden["unit_spherical_grid"].items():
+        az, el = syn.unit_spherical_grid(int(n))
+        assert np.allclose(az, g["azim"], atol=1e-9) and np.allclose(el, g["elev"], atol=1e-9), n
+
+
+def test_selector_buffers_match_reference(golden):
+    for key, g in golden["selectors"].items():
+        cfg, V = key.split("_")
+        V = int(V)
+        if cfg == "circular" or V == 4:  # models/mvtn.py:303: spherical with 4 views falls back to circular
+            az, el, di = syn.circular_views(V, 30.0, 2.2)
+        else:
+            az, el, di = syn.spherical_views(V, 2.2)
+        assert np.allclose(az, g["azim"], atol=1e-4), key
+        assert np.allclose(el, g["elev"], atol=1e-4), key
+        assert np.array_equal(di, np.asarray(g["dist"], np.float32)), key
+        assert g["stride"] == [0, 1]  # the selectors hand the renderer stride-(0,1) expanded views
+
+
+def test_flatten_order_matches_batch_tensor(golden):
+    x = torch.arange(6.0).reshape(2, 3)
+    assert batch_tensor(x.T, dim=1, squeeze=True).tolist() == golden["batch_tensor_2x3"]
+    assert flatten_views(x).tolist() == golden["batch_tensor_2x3"]
+    xe = torch.arange(4.0).expand(3, 4)  # stride (0,1), as MVTN's selectors produce
+    assert flatten_views(xe).tolist() == golden["batch_tensor_expanded_3x4"]
+    assert batch_tensor(xe.T, dim=1, squeeze=True).tolist() == golden["batch_tensor_expanded_3x4"]
+
+
+def test_relayout_equivalence(golden):
+    """models/renderer.py:109-113 replayed with our unbatch_tensor: images[b,v,c] == raw[b*V+v,:,:,c]."""
+    B, V, H, W = 3, 4, 5, 6
+    raw = torch.arange(B * V * H * W * 4, dtype=torch.float32).reshape(B * V, H, W, 4)
+    img = unbatch_tensor(raw.clone(), batch_size=V, dim=1, unsqueeze=True).transpose(0, 1)
+    img = img[..., 0:3].transpose(2, 4).transpose(3, 4)
+    assert list(img.shape) == golden["relayout"]["shape"] and golden["relayout"]["matches_n_eq_bV_plus_v"]
+    ours = raw[..., :3].permute(0, 3, 1, 2).reshape(B, V, 3, H, W)  # what the HIP kernel writes directly
+    assert torch.equal(img, ours)
+
+
+def test_torch_color_matches_reference(golden):
+    for name, g in golden["torch_color"].items():
+        assert torch_color(name).tolist() == g["plain"]
+        got = torch_color(name, max_lightness=True).numpy()
+        assert [int(x) for x in got.view(np.uint32)] == g["max_lightness_bits"], name
+    torch.manual_seed(0)
+    c = torch_color("random", max_lightness=True)
+    assert c.shape == (3,) and float(c.max()) < 1.0 and float(c.max()) > 0.9999
+    assert torch_color("custom", custom_color=(0.1, 0.2, 0.3)).tolist() == pytest.approx([0.1, 0.2, 0.3])
+    with pytest.raises(ValueError):
+        torch_color("chartreuse")
+
+
+def test_check_valid_rotation_matrix_matches_reference(golden):
+    g = golden["check_valid_rotation_matrix"]
+    eye = torch.eye(3)[None]
+    m = eye.clone(); m[0, 0, 0] = 1.0001
+    assert check_valid_rotation_matrix(eye) == g["identity"] and check_valid_rotation_matrix(m) == g["diag_1.0001"]
+    m = eye.clone(); m[0, 0, 1] = 2e-6
+    assert check_valid_rotation_matrix(m) == g["offdiag_2e-6"]
+    m = eye.clone(); m[0, 0, 1] = 5e-7
+    assert check_valid_rotation_matrix(m) == g["offdiag_5e-7"]
+
+
+def test_center_and_normalize_matches_reference(golden):
+    g = golden["center_and_normalize"]
+    got = syn.center_and_normalize(np.asarray(g["in"], np.float64))
+    assert np.allclose(got, g["out"], atol=2e-6)
+
+
+def test_synthetic_meshes():
+    for tier, (nv, nf) in {"S": (642, 1280), "M": (2562, 5120), "L": (10242, 20480)}.items():
+        v, f = syn.synthetic_mesh(tier, 0)
+        assert v.shape == (nv, 3) and f.shape == (nf, 3) and v.dtype == np.float32 and f.dtype == np.int64
+        assert abs(np.linalg.norm(v, axis=1).max() - 1) < 1e-6 and np.abs(v.mean(0)).max() < 1e-6
+        # closed, consistently outward-wound: signed volume positive, every edge shared by two faces
+        a, b, c = (v[f[:, k]].astype(np.float64) for k in range(3))
+        assert np.einsum("ij,ij->i", a, np.cross(b, c)).sum() > 0
+    v2, _ = syn.synthetic_mesh("M", 0)
+    v3, _ = syn.synthetic_mesh("M", 1)
+    assert np.array_equal(v2, syn.synthetic_mesh("M", 0)[0]) and not np.array_equal(v2, v3)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """libmvr_hip.so loads without a GPU and exports exactly what include/mvr.h declares."""
+    from mvtn_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "mvr.h")).read()
+    declared = set(re.findall(r"\b(mvr_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), "libmvr_hip.so does not export %s" % name
+    assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
+    assert lib.mvr_version() >= 100
+    # struct layouts agree with the header (sizes computed by hand from include/mvr.h)
+    assert ctypes.sizeof(_lib.MeshBatch) == 6 * 4 + 5 * 8
+    assert ctypes.sizeof(_lib.MeshParams) == 6 * 4 + 5 * 4 + 6 * 4
+    assert ctypes.sizeof(_lib.PointsParams) == 6 * 4 + 8 + 6 * 4
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Argument errors are reported before any HIP call, so they can be exercised on a CPU-only box."""
+    from mvtn_amd import _lib
+    lib = _lib.load()
+    assert lib.mvr_look_at(None, None, None, 4, None, None, None, None, None) == 1
+    assert b"bad argument" in lib.mvr_last_error()
+    mb = _lib.MeshBatch(0, 0, 0, 0, 0, 0, None, None, None, None, None)
+    mp = _lib.MeshParams(1, 8, 8, 0, 1, 0, 60.0, 0.5, 0.3, 0.2, 64.0)
+    assert lib.mvr_render_meshes_forward(mb, mp, None, None, None, None, None, None, 0, None) == 1
+    pp = _lib.PointsParams(1, 10, 1, 8, 8, 0, -1.0)
+    assert lib.mvr_render_points_forward(pp, None, None, None, None, None, None, None, None, 0, None) == 1
+    assert lib.mvr_mesh_workspace_bytes(None, None) == 0
+
+
+def test_product_has_no_cpu_fallback_and_never_imports_the_oracle():
+    import mvtn_amd
+    from mvtn_amd import MVRenderer
+    r = MVRenderer(2, 16, pc_rendering=False)
+    with pytest.raises(RuntimeError):
+        r(None, None, torch.zeros(1, 2), torch.zeros(1, 2), torch.ones(1, 2))
+    pkg = os.path.dirname(mvtn_amd.__file__)
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, fn
+
+
+def test_packed_meshes_layout():
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = zip(syn.synthetic_mesh("S", 0), syn.cad_soup(1), syn.synthetic_mesh("M", 2))
+    ms = Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl])
+    assert len(ms) == 3 and len(ms[1].verts_list()) == 1 and ms.verts_padded().shape == (3, 2562, 3)
+    for src in (ms, [ms[i] for i in range(3)]):  # batched object or list of single-mesh objects (both reference forms)
+        p = PackedMeshes.from_meshes(src, "cpu")
+        assert p.n_meshes == 3 and p.total_verts == sum(len(v) for v in vl) and p.total_faces == sum(len(f) for f in fl)
+        assert p.max_verts == 2562 and p.max_faces == 5120 and p.faces.dtype == torch.int32
+        assert p.vert_off.tolist() == [0, 642, 642 + len(vl[1]), p.total_verts]
+        assert torch.equal(p.faces[int(p.face_off[1]):int(p.face_off[2])], torch.from_numpy(fl[1]).to(torch.int32))
+    with pytest.raises(ValueError):
+        PackedMeshes.from_meshes(Meshes([torch.zeros(3, 3)], [torch.tensor([[0, 1, 3]])]), "cpu")
+    col = torch.rand(3, 2562, 3)
+    p = PackedMeshes.from_meshes(ms, "cpu", vert_colors=col)
+    assert torch.equal(p.vert_colors[642:642 + len(vl[1])], col[1, :len(vl[1])])
+
+
+def test_cameras_object():
+    from mvtn_amd.structures import Cameras
+    from oracle import oracle as orc
+    R, T = orc.look_at([10.0, 200.0], [20.0, -40.0], [2.2, 1.5])
+    cam = Cameras(torch.from_numpy(R), torch.from_numpy(T))
+    C = orc.camera_position([10.0, 200.0], [20.0, -40.0], [2.2, 1.5])
+    assert np.allclose(cam.get_camera_center().numpy(), C, atol=1e-5)
+    # util.py:604-618 plot_cameras: world-to-view inverse maps the view-space origin to the camera centre
+    pts = cam.get_world_to_view_transform().inverse().transform_points(torch.zeros(1, 3))
+    assert np.allclose(pts[:, 0].numpy(), C, atol=1e-5)
+
+
+def test_mvrenderer_mode_switches():
+    """models/renderer.py:153-171: random colour / random light only in training mode."""
+    from mvtn_amd import MVRenderer
+    r = MVRenderer(4, 32, pc_rendering=False, object_color="random", light_direction="random")
+    r.train()
+    np.random.seed(0)
+    torch.manual_seed(0)
+    c1, l1 = r.rendering_color(), r.light_direction(None, None, None)
+    c2, l2 = r.rendering_color(), r.light_direction(None, None, None)
+    assert not torch.equal(c1, c2) and l1 != l2 and len(l1) == 1 and len(l1[0]) == 3
+    r.eval()
+    assert torch.equal(r.rendering_color(), torch_color("white"))
+    assert MVRenderer(4, 32, light_direction="fixed").light_direction(None, None, None) == ((0, 1.0, 0),)
+    assert MVRenderer(4, 32, object_color="custom").rendering_color((0.1, 0.2, 0.3)) == (0.1, 0.2, 0.3)
+    with pytest.raises(NotImplementedError):
+        MVRenderer(4, 32, points_per_pixel=5)
+    with pytest.raises(ValueError):
+        MVRenderer(4, 32, rotation_check="maybe")

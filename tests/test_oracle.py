@@ -1,0 +1,225 @@
+"""CPU (-m "not gpu"): the oracle against the golden caller-side fixtures and analytic known-answer
+tests.  The pixel arithmetic itself is "parity unpinned": the
+reference holds no golden vector for it (PyTorch3D is neither vendored nor installable), so these
+closed-form checks are what pins the oracle."""
+import numpy as np
+import pytest
+
+from mvtn_amd import synthetic as syn
+
+
+def test_oracle_builds_and_exports(oracle):
+    lib = oracle.lib()
+    for name in ("orc_look_at", "orc_camera_position", "orc_check_rotation", "orc_vertex_normals",
+                 "orc_render_meshes", "orc_render_points"):
+        for sfx in ("_f32", "_f64"):
+            assert hasattr(lib, name + sfx)
+
+
+def test_ka1_look_at_origin_and_centre(oracle, golden):
+    """KA1: origin -> view (0,0,d); T = (0,0,d); camera centre -R T = C; R orthonormal, det 1."""
+    sel = golden["selectors"]["spherical_12"]
+    az, el, di = np.array(sel["azim"]), np.array(sel["elev"]), np.array(sel["dist"])
+    for dtype, tol in ((np.float32, 2e-6), (np.float64, 1e-14)):
+        R, T = oracle.look_at(az, el, di, dtype)
+        C = oracle.camera_position(az, el, di, dtype)
+        assert np.abs(T - np.stack([0 * di, 0 * di, di], 1)).max() < tol * 10
+        centre = -np.einsum("nij,nj->ni", R, T)
+        assert np.abs(centre - C).max() < tol * 10
+        assert np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)).max() < tol
+        assert np.abs(np.linalg.det(R.astype(np.float64)) - 1).max() < tol * 2
+        # the camera looks at the origin along +z of the view frame: (0 - C) R = (0, 0, d) - T ... = view of origin
+        view_origin = np.einsum("ni,nij->nj", np.zeros_like(C), R) + T
+        assert np.abs(view_origin[:, :2]).max() < tol * 10
+
+
+def test_camera_position_closed_form(oracle):
+    a, e, d = np.array([0.0, 90.0, 180.0, 30.0]), np.array([0.0, 0.0, 45.0, -60.0]), np.array([2.2, 1.0, 3.0, 2.0])
+    C = oracle.camera_position(a, e, d, np.float64)
+    ar, er = np.radians(a), np.radians(e)
+    want = np.stack([d * np.cos(er) * np.sin(ar), d * np.sin(er), d * np.cos(er) * np.cos(ar)], 1)
+    assert np.abs(C - want).max() < 1e-12
+
+
+def test_ka10_rotation_validity(oracle, golden):
+    """check_valid_rotation_matrix (util.py:403-420): golden outcomes + the degenerate band near the pole."""
+    g = golden["check_valid_rotation_matrix"]
+    eye = np.eye(3, dtype=np.float32)[None]
+    cases = {"identity": eye.copy(), "diag_1.0001": eye.copy(), "offdiag_2e-6": eye.copy(),
+             "offdiag_5e-7": eye.copy(), "diag_1.000005": eye.copy()}
+    cases["diag_1.0001"][0, 0, 0] = 1.0001
+    cases["offdiag_2e-6"][0, 0, 1] = 2e-6
+    cases["offdiag_5e-7"][0, 0, 1] = 5e-7
+    cases["diag_1.000005"][0, 0, 0] = 1.000005
+    for k, M in cases.items():
+        assert oracle.check_rotation(M)[0] == g[k], k
+    # elev = 89.9999: |x| between the 5e-3 repair threshold and unit -> invalid; exactly 90: repaired -> valid
+    R, _ = oracle.look_at([0.0, 0.0, 0.0], [89.9999, 90.0, 30.0], [2.2, 2.2, 2.2])
+    ok, flags = oracle.check_rotation(R)
+    assert list(flags) == [False, True, True] and not ok
+
+
+def _sphere(level=5):
+    v, f = syn.icosphere(level)
+    return v.astype(np.float32), f
+
+
+def test_ka2_sphere_silhouette(oracle):
+    """KA2: unit sphere at d = 2.2, fov 60 deg: silhouette = disc of NDC radius 1/(tan30 sqrt(d^2-1)) = 0.88388
+    -> 61.36 % of the pixels as the tessellation is refined."""
+    v, f = _sphere(5)
+    out = oracle.render_meshes([v], [f], [[30.0]], [[20.0]], [[2.2]], 224)
+    frac = (out["pix_to_face"] >= 0).mean()
+    r = 1.0 / (np.tan(np.radians(30.0)) * np.sqrt(2.2 ** 2 - 1))
+    assert abs(r - 0.88388) < 1e-5
+    assert abs(frac - np.pi * r * r / 4) < 0.004
+    # depth of the nearest point of the sphere is d - 1
+    assert abs(out["zbuf"][out["pix_to_face"] >= 0].min() - 1.2) < 2e-3
+
+
+def _tri_mesh(tris):
+    verts = np.asarray(tris, np.float32).reshape(-1, 3)
+    faces = np.arange(len(verts)).reshape(-1, 3).astype(np.int64)
+    return verts, faces
+
+
+def test_ka3_fronto_parallel_triangle_exact_coverage(oracle):
+    """KA3: camera at (0,0,d) looking at the origin (azim=elev=0).  World (x,y,0) -> view (-x, y, d) -> NDC
+    (-s x/d, s y/d).  A triangle with vertices on the pixel lattice covers exactly the pixel centres with all
+    three barycentrics strictly positive."""
+    S, d = 16, 2.0
+    s = 1.0 / np.tan(np.radians(30.0))
+    ndc = np.array([[-0.75, -0.75], [0.75, -0.75], [-0.75, 0.75]])  # lattice-aligned right triangle (edges on pixel borders)
+    world = np.stack([-ndc[:, 0] * d / s, ndc[:, 1] * d / s, np.zeros(3)], 1)
+    v, f = _tri_mesh([world])
+    out = oracle.render_meshes([v], [f], [[0.0]], [[0.0]], [[d]], S, perspective_correct=False)
+    p2f = out["pix_to_face"][0]
+    centres = -1 + (2 * np.arange(S) + 1) / S
+    want = np.zeros((S, S), bool)
+    for i in range(S):          # output row i <-> y = centres[S-1-i]
+        for j in range(S):      # output col j <-> x = centres[S-1-j]
+            x, y = centres[S - 1 - j], centres[S - 1 - i]
+            want[i, j] = (x > -0.75) and (y > -0.75) and (x + y < 0.0)
+    assert np.array_equal(p2f >= 0, want)
+    assert np.allclose(out["zbuf"][0][want], d, atol=1e-6)
+    b = out["bary"][0][want]
+    assert np.allclose(b.sum(1), 1.0, atol=1e-5) and (b > 0).all()
+
+
+def test_ka4_coincident_faces_lower_index_wins(oracle):
+    tri = [[-0.5, -0.5, 0.0], [0.5, -0.5, 0.0], [0.0, 0.6, 0.0]]
+    v, f = _tri_mesh([tri, tri, tri])
+    for mode in (0, 1):
+        out = oracle.render_meshes([v], [f], [[0.0]], [[0.0]], [[2.2]], 32, mode=mode)
+        assert set(np.unique(out["pix_to_face"])) == {-1, 0}
+    # reversed order of a NEARER triangle: depth beats index
+    near = [[-0.5, -0.5, 0.3], [0.5, -0.5, 0.3], [0.0, 0.6, 0.3]]
+    v, f = _tri_mesh([tri, near])
+    out = oracle.render_meshes([v], [f], [[0.0]], [[0.0]], [[2.2]], 32)
+    assert set(np.unique(out["pix_to_face"])) == {-1, 1}
+
+
+def test_ka5_plane_shading_closed_form(oracle):
+    """KA5: constant-normal plane lit by (0,1,0): colour = (0.5 + 0.3 max(0, n_y)) c + 0.2 alpha^64."""
+    # a large quad facing the camera at (0,0,d): normal (0,0,1) (both triangles CCW seen from +z), tilted cases via light
+    q = [[-2, -2, 0], [2, -2, 0], [2, 2, 0], [-2, 2, 0]]
+    v = np.asarray(q, np.float32)
+    f = np.asarray([[0, 1, 2], [0, 2, 3]], np.int64)
+    nrm = oracle.vertex_normals(v, f)
+    assert np.allclose(nrm, [[0, 0, 1]] * 4, atol=1e-6)
+    c = 0.99999
+    for light, cosang in (((0.0, 1.0, 0.0), 0.0), ((0.0, 0.0, 1.0), 1.0), ((0.0, 1.0, 1.0), np.sqrt(0.5))):
+        out = oracle.render_meshes([v], [f], [[0.0]], [[0.0]], [[2.2]], 8, light_dir=[light], obj_color=(c, c, c))
+        img = out["images"][0, 0]  # (3,H,W); covered except centres exactly on the shared diagonal (strict > 0 rule)
+        assert (out["pix_to_face"] >= 0).mean() > 0.8
+        # specular: view dir = normalize(C - p); reflect = -l + 2 cos n ; closed form per pixel
+        s = 1.0 / np.tan(np.radians(30.0))
+        centres = -1 + (2 * np.arange(8) + 1) / 8
+        for i in (0, 3, 7):
+            for j in (1, 4, 6):
+                if out["pix_to_face"][0, i, j] < 0:
+                    continue  # on the diagonal
+                xn, yn = centres[7 - j], centres[7 - i]
+                p = np.array([-xn * 2.2 / s, yn * 2.2 / s, 0.0])
+                vh = np.array([0, 0, 2.2]) - p
+                vh /= np.linalg.norm(vh)
+                l = np.asarray(light, float) / np.linalg.norm(light)
+                r = -l + 2 * cosang * np.array([0, 0, 1.0])
+                alpha = max(0.0, float(vh @ r)) * (1.0 if cosang > 0 else 0.0)
+                want = (0.5 + 0.3 * max(0.0, cosang)) * c + 0.2 * alpha ** 64
+                assert abs(img[0, i, j] - want) < 2e-5, (light, i, j, img[0, i, j], want)
+
+
+def test_ka6_background_is_099999(oracle, golden):
+    bits = golden["torch_color"]["white"]["max_lightness_bits"][0]
+    white = np.array([bits], np.uint32).view(np.float32)[0]
+    assert abs(float(white) - 0.99999) < 1e-7
+    v, f = syn.synthetic_mesh("S", 0)
+    out = oracle.render_meshes([v], [f], [[10.0]], [[20.0]], [[2.2]], 32, bg_color=(white,) * 3)
+    bg = out["pix_to_face"][0] < 0
+    assert bg.any() and (out["images"][0, 0][:, bg] == white).all()
+
+
+def test_ka7_point_hits(oracle):
+    """KA7: r = 0.006 < pixel half-diagonal at 224^2 (0.00631): a point at an NDC pixel CORNER hits nothing; a point
+    at a pixel centre hits exactly that pixel."""
+    S, d = 224, 1.0
+    R, T = oracle.look_at([0.0], [0.0], [d], np.float64)
+
+    def world_of(ndc_x, ndc_y, z=1.0):
+        view = np.array([ndc_x, ndc_y, z])
+        return ((view - T[0]) @ R[0].T) * d
+    corner = world_of(0.0, 0.0)                       # NDC (0,0) is a corner shared by 4 pixels when S is even
+    centre = world_of(-1 + (2 * 100 + 1) / S, -1 + (2 * 50 + 1) / S)
+    for pt, want_hits in ((corner, 0), (centre, 1)):
+        out = oracle.render_points(np.asarray([[pt]], np.float32), [[0.0]], [[0.0]], [[d]], S, radius=0.006,
+                                   obj_color=(1, 0, 0), bg_color=(0, 0, 0))
+        assert int((out["idx"] >= 0).sum()) == want_hits
+    i, j = np.argwhere(out["idx"][0] >= 0)[0]
+    assert (i, j) == (S - 1 - 50, S - 1 - 100)
+    assert np.allclose(out["images"][0, 0][:, i, j], [1, 0, 0], atol=1e-6)
+    # nearer point wins; ties -> smaller index
+    pts = np.asarray([[world_of(0.1, 0.1, 1.5), world_of(0.1, 0.1, 0.7), world_of(0.1, 0.1, 0.7)]], np.float32)
+    out = oracle.render_points(pts, [[0.0]], [[0.0]], [[d]], 64, radius=0.05)
+    assert set(np.unique(out["idx"])) == {-1, 1}
+
+
+def test_naive_and_fast_loops_agree(oracle):
+    """mode 0 (literal pixel-major PyTorch3D loop) == mode 1 (face-major) bit for bit, meshes and points."""
+    vl, fl = zip(syn.synthetic_mesh("S", 3), syn.cad_soup(1))
+    az, el, di = [[10.0, 200.0]] * 2, [[-30.0, 50.0]] * 2, [[2.2, 1.8]] * 2
+    for persp in (True, False):
+        a = oracle.render_meshes(vl, fl, az, el, di, 48, mode=0, perspective_correct=persp)
+        b = oracle.render_meshes(vl, fl, az, el, di, 48, mode=1, perspective_correct=persp)
+        for k in ("images", "pix_to_face", "zbuf", "bary"):
+            assert np.array_equal(a[k], b[k]), k
+    pts = np.stack([syn.surface_points(v, f, 400, 0) for v, f in zip(vl, fl)])
+    a = oracle.render_points(pts, az, el, [[1.0, 1.3]] * 2, 64, radius=0.03, mode=0)
+    b = oracle.render_points(pts, az, el, [[1.0, 1.3]] * 2, 64, radius=0.03, mode=1)
+    for k in ("images", "idx", "zbuf", "dist2"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_view_order_and_layout(oracle):
+    """n = b*V + v (golden: batch_tensor order) and images[b, v, c, i, j] planar."""
+    vl, fl = zip(syn.synthetic_mesh("S", 0), syn.synthetic_mesh("S", 1))
+    az = np.array([[0.0, 90.0, 180.0], [45.0, 135.0, 270.0]])
+    el = np.full((2, 3), 20.0)
+    di = np.full((2, 3), 2.2)
+    full = oracle.render_meshes(vl, fl, az, el, di, 32)
+    for b in range(2):
+        for v in range(3):
+            one = oracle.render_meshes([vl[b]], [fl[b]], az[b:b + 1, v:v + 1], el[b:b + 1, v:v + 1], di[b:b + 1, v:v + 1], 32)
+            assert np.array_equal(one["images"][0, 0], full["images"][b, v])
+            assert np.array_equal(one["pix_to_face"][0], full["pix_to_face"][b * 3 + v])
+
+
+def test_points_scale_by_inverse_distance(oracle):
+    """Pointclouds.scale_(1/dist) (models/renderer.py:142-143): with an orthographic camera the image of a cloud
+    at distance d equals the image of the cloud pre-scaled by 1/d' ... i.e. doubling dist halves the footprint."""
+    v, f = syn.synthetic_mesh("S", 0)
+    pts = syn.surface_points(v, f, 2000, 0)[None]
+    a = oracle.render_points(pts, [[30.0]], [[10.0]], [[1.0]], 64, radius=0.04)
+    b = oracle.render_points(pts, [[30.0]], [[10.0]], [[2.0]], 64, radius=0.04)
+    ca, cb = (a["idx"] >= 0).sum(), (b["idx"] >= 0).sum()
+    assert 0.2 < cb / ca < 0.45  # ~ (1/2)^2 of the covered area, thickened by the fixed radius
