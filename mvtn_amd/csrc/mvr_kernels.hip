@@ -404,6 +404,53 @@ __device__ __forceinline__ void decode_block(int bid, int n_strips, int views_pe
   *strip = j % n_strips;
 }
 
+// ---- shading of a resolved pixel (device fast path) -------------------------------------------------
+// Coverage and depth order are already decided (bit-exactly) when this runs; the colour itself only has to
+// meet the 1e-4 pixel tolerance, so it uses the hardware reciprocal / reciprocal-square-root (1 ulp) and lets
+// the compiler contract multiply-adds.  Same formulas as mvr::phong_pixel (the exact restatement used by the
+// backward kernel and the host tests); observed difference ~1e-6.
+struct ShadeConst {
+  f3 lh;            // normalised light direction (per view)
+  f3 cc;            // camera centre
+  f3 objc;
+  float ambient, diffuse, specular, shininess;
+  const float4 *vat;
+  const float *vcol;
+};
+
+__device__ __forceinline__ f3 shade_fast(const f3 &P0, const f3 &P1, const f3 &P2, float px, float py, bool persp,
+                                         const f3 &X0, const f3 &X1, const f3 &X2, const f3 &N0, const f3 &N1, const f3 &N2,
+                                         const f3 &c0, const f3 &c1, const f3 &c2, const ShadeConst &sh) {
+#pragma clang fp contract(fast)
+  const float e0 = (px - P1.x) * (P2.y - P1.y) - (py - P1.y) * (P2.x - P1.x);
+  const float e1 = (px - P2.x) * (P0.y - P2.y) - (py - P2.y) * (P0.x - P2.x);
+  const float e2 = (px - P0.x) * (P1.y - P0.y) - (py - P0.y) * (P1.x - P0.x);
+  const float area = ((P2.x - P0.x) * (P1.y - P0.y) - (P2.y - P0.y) * (P1.x - P0.x)) + mvr::kEps;
+  const float ra = __builtin_amdgcn_rcpf(area);
+  float w0 = e0 * ra, w1 = e1 * ra, w2 = e2 * ra;
+  if (persp) {
+    const float t0 = w0 * P1.z * P2.z, t1 = P0.z * w1 * P2.z, t2 = P0.z * P1.z * w2;
+    const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, mvr::kEps));
+    w0 = t0 * rd; w1 = t1 * rd; w2 = t2 * rd;
+  }
+  const f3 p = {w0 * X0.x + w1 * X1.x + w2 * X2.x, w0 * X0.y + w1 * X1.y + w2 * X2.y, w0 * X0.z + w1 * X1.z + w2 * X2.z};
+  const f3 nn = {w0 * N0.x + w1 * N1.x + w2 * N2.x, w0 * N0.y + w1 * N1.y + w2 * N2.y, w0 * N0.z + w1 * N1.z + w2 * N2.z};
+  const f3 tex = {w0 * c0.x + w1 * c1.x + w2 * c2.x, w0 * c0.y + w1 * c1.y + w2 * c2.y, w0 * c0.z + w1 * c1.z + w2 * c2.z};
+  const float eps2 = mvr::kNormalizeEps * mvr::kNormalizeEps;
+  const float rn = __builtin_amdgcn_rsqf(fmaxf(nn.x * nn.x + nn.y * nn.y + nn.z * nn.z, eps2));  // v / max(|v|, eps)
+  const f3 nh = {nn.x * rn, nn.y * rn, nn.z * rn};
+  const float cosang = nh.x * sh.lh.x + nh.y * sh.lh.y + nh.z * sh.lh.z;
+  const f3 view = {sh.cc.x - p.x, sh.cc.y - p.y, sh.cc.z - p.z};
+  const float rv = __builtin_amdgcn_rsqf(fmaxf(view.x * view.x + view.y * view.y + view.z * view.z, eps2));
+  const float two_c = 2.0f * cosang;
+  const f3 refl = {two_c * nh.x - sh.lh.x, two_c * nh.y - sh.lh.y, two_c * nh.z - sh.lh.z};
+  const float dvr = (view.x * refl.x + view.y * refl.y + view.z * refl.z) * rv;
+  const float alpha = cosang > 0.0f ? fmaxf(dvr, 0.0f) : 0.0f;
+  const float spec = sh.specular * mvr::pow_shininess(alpha, sh.shininess);
+  const float sc = sh.ambient + sh.diffuse * fmaxf(cosang, 0.0f);
+  return {sc * tex.x + spec, sc * tex.y + spec, sc * tex.z + spec};
+}
+
 // Exact-conservative candidate pixel range of a face inside the strip; returns the number of candidates
 // (0: the face cannot touch a pixel centre of this strip).
 __device__ __forceinline__ int face_range(const mvr::FaceSetup<float> &fs, int W, int H, int jy_lo, int jy_hi,
@@ -442,7 +489,7 @@ __device__ __forceinline__ void unpack_face(const FaceCoef &q, mvr::FaceSetup<fl
 //              the prefix sums) -> no lane waits for another lane's big triangle; any face size is handled by
 //              the same loop.  Depth resolve: 64-bit LDS atomicMin on (float_bits(z) << 32 | face).
 //   shade    : every pixel of the strip: winner -> barycentrics -> Phong + hard blend -> planar store.
-__global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
+__global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int W = a.W, H = a.H, TH = a.TH;
   unsigned long long *keys = (unsigned long long *)smem;                       // TH * W
@@ -480,12 +527,18 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
   unsigned long long t_scan = 0, t_small = 0, t_large = 0, n_small_tot = 0, n_large_tot = 0;
   unsigned long long tc0 = clock64();
 #endif
+  uint2 q_next = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  if (tid * MVR_SCAN_PER_LANE < nf) q_next = *reinterpret_cast<const uint2 *>(bins + tid * MVR_SCAN_PER_LANE);
   for (int base = 0; base < nf; base += MVR_BLOCK * MVR_SCAN_PER_LANE) {
     // ---- scan: 4 faces (one 8-byte vector of row-bin ranges) per lane; compact hits into the LDS list ----
     const int f0 = base + tid * MVR_SCAN_PER_LANE;
+    const uint2 q = q_next;
+    {  // prefetch the next round's vector: its latency hides behind this round's ballots / raster batches
+      const int fn = f0 + MVR_BLOCK * MVR_SCAN_PER_LANE;
+      if (fn < nf) q_next = *reinterpret_cast<const uint2 *>(bins + fn);
+    }
     unsigned hit = 0;
     if (f0 < nf) {
-      const uint2 q = *reinterpret_cast<const uint2 *>(bins + f0);
       const unsigned w[2] = {q.x, q.y};
 #pragma unroll
       for (int k = 0; k < MVR_SCAN_PER_LANE; ++k) {
@@ -506,7 +559,9 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
         if (h) list[bs + __popcll(mh & ((1ull << lane) - 1ull))] = f0 + k;
       }
     }
-    __syncthreads();
+    // LDS-only barrier: a plain __syncthreads() would also wait for the prefetched global load (vmcnt(0))
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
     const int n_list = cnt[0];
     const bool last = base + MVR_BLOCK * MVR_SCAN_PER_LANE >= nf;
     if (!last && n_list + MVR_BLOCK * MVR_SCAN_PER_LANE <= MVR_LIST_CAP) continue;  // room for a worst-case scan round
@@ -625,52 +680,92 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_raster_shade(RasterArgs a) {
   }
 #endif
 
-  // ---- resolve + shade + store ------------------------------------------------------------
-  float Rm[9], Tv[3];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) Rm[k] = a.R[9 * (size_t)n + k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) Tv[k] = a.T[3 * (size_t)n + k];
-  const f3 cc = mvr::camera_center<float>(Rm, Tv);
-  const float *lp = a.light + 3 * (size_t)(a.n_light == 1 ? 0 : n);
-  const f3 light = {lp[0], lp[1], lp[2]};
-  const mvr::Phong<float> ph = {a.ambient, a.diffuse, a.specular, a.shininess};
-  const f3 objc = {a.obj[0], a.obj[1], a.obj[2]};
-  const float4 *__restrict__ vat = a.vattr + 2 * (size_t)vo;
-  const float *__restrict__ vcol = a.m.vert_colors ? a.m.vert_colors + 3 * (size_t)vo : nullptr;
+  // ---- resolve: background pixels are stored at once; covered pixels are COMPACTED into an LDS list so
+  //      the shading arithmetic below runs with every lane busy (coverage is ~40 % of the frame) ----------
   const size_t HW = (size_t)H * W;
   float *__restrict__ img = a.images + (size_t)n * 3 * HW + (size_t)r0 * W;
   int32_t *__restrict__ p2f = a.p2f ? a.p2f + (size_t)n * HW + (size_t)r0 * W : nullptr;
-  int row = tid / W, col = tid - row * W;
-  const int drow = MVR_BLOCK / W, dcol = MVR_BLOCK - drow * W;
-#pragma unroll 2
-  for (int pix = tid; pix < rows * W; pix += MVR_BLOCK, row += drow, col += dcol) {
-    if (col >= W) { col -= W; ++row; }
-    unsigned long long key = keys[pix];
-    float cr = a.bg[0], cg = a.bg[1], cb = a.bg[2];
-    int face = -1;
-    if (key != MVR_KEY_EMPTY) {
-      face = (int)(unsigned)(key & 0xffffffffull);
-      int i0 = faces[3 * face], i1 = faces[3 * face + 1], i2 = faces[3 * face + 2];
-      mvr::FaceSetup<float> fs = mvr::face_setup<float>(ld3(proj + i0), ld3(proj + i1), ld3(proj + i2), cull);
-      float w0, w1, w2, pz;
-      mvr::face_bary<float>(fs, -1.0f + mvr::div_by(2.0f * (float)(W - 1 - col) + 1.0f, fW, invW),
-                            -1.0f + mvr::div_by(2.0f * (float)(jy_hi - row) + 1.0f, fH, invH), persp, &w0, &w1, &w2, &pz);
-      f3 c0 = objc, c1 = objc, c2 = objc;
-      if (vcol) {
-        c0 = {vcol[3 * i0], vcol[3 * i0 + 1], vcol[3 * i0 + 2]};
-        c1 = {vcol[3 * i1], vcol[3 * i1 + 1], vcol[3 * i1 + 2]};
-        c2 = {vcol[3 * i2], vcol[3 * i2 + 1], vcol[3 * i2 + 2]};
+  ShadeConst sh;
+  {
+    float Rm[9], Tv[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rm[k] = a.R[9 * (size_t)n + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Tv[k] = a.T[3 * (size_t)n + k];
+    sh.cc = mvr::camera_center<float>(Rm, Tv);
+    const float *lp = a.light + 3 * (size_t)(a.n_light == 1 ? 0 : n);
+    sh.lh = mvr::normalize<float>({lp[0], lp[1], lp[2]}, mvr::kNormalizeEps);
+    sh.objc = {a.obj[0], a.obj[1], a.obj[2]};
+    sh.ambient = a.ambient; sh.diffuse = a.diffuse; sh.specular = a.specular; sh.shininess = a.shininess;
+    sh.vat = a.vattr + 2 * (size_t)vo;
+    sh.vcol = a.m.vert_colors ? a.m.vert_colors + 3 * (size_t)vo : nullptr;
+  }
+
+  int *plist = (int *)coef;                       // the batch records are dead now: reuse their LDS
+  const int plist_cap = (int)((sizeof(FaceCoef) + sizeof(int2)) * MVR_BATCH / sizeof(int));
+  const int n_pix = rows * W;
+  if (tid == 0) cnt[0] = 0;
+  __syncthreads();
+  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  for (int pbase = 0; pbase < n_pix; pbase += plist_cap) {
+    const int pend = min(n_pix, pbase + plist_cap);
+    for (int p0 = pbase; p0 < pend; p0 += MVR_BLOCK) {   // uniform trip count: ballots need every lane
+      const int pix = p0 + tid;
+      const bool in = pix < pend;
+      const bool covered = in && keys[in ? pix : 0] != MVR_KEY_EMPTY;
+      if (in && !covered) {
+        img[pix] = bg0; img[HW + pix] = bg1; img[2 * HW + pix] = bg2;
+        if (p2f) p2f[pix] = -1;
       }
-      f3 rgb = mvr::phong_pixel<float>(w0, w1, w2, ld3(vat + 2 * i0), ld3(vat + 2 * i1), ld3(vat + 2 * i2),
-                                       ld3(vat + 2 * i0 + 1), ld3(vat + 2 * i1 + 1), ld3(vat + 2 * i2 + 1),
-                                       c0, c1, c2, light, cc, ph);
-      cr = rgb.x; cg = rgb.y; cb = rgb.z;
+      unsigned long long mc = __ballot(covered);
+      if (mc) {
+        int bs = 0;
+        if (lane == 0) bs = atomicAdd(&cnt[0], __popcll(mc));
+        bs = __shfl(bs, 0);
+        if (covered) plist[bs + __popcll(mc & ((1ull << lane) - 1ull))] = pix;
+      }
     }
-    img[pix] = cr;
-    img[HW + pix] = cg;
-    img[2 * HW + pix] = cb;
-    if (p2f) p2f[pix] = face;
+    __syncthreads();
+    const int n_cov = cnt[0];
+    // ---- shade the covered pixels (dense).  Software-pipelined: the index chain of the NEXT pixel
+    //      (LDS list -> LDS key -> face's vertex indices from L2) is issued before the current pixel's
+    //      9 attribute gathers are consumed, so the two dependent latencies overlap. ------------------------
+    int e = tid;
+    int pix = 0, face = 0, i0 = 0, i1 = 0, i2 = 0;
+    if (e < n_cov) {
+      pix = plist[e];
+      face = (int)(unsigned)(keys[pix] & 0xffffffffull);
+      i0 = faces[3 * face]; i1 = faces[3 * face + 1]; i2 = faces[3 * face + 2];
+    }
+    while (e < n_cov) {
+      const f3 P0 = ld3(proj + i0), P1 = ld3(proj + i1), P2 = ld3(proj + i2);
+      const f3 X0 = ld3(sh.vat + 2 * i0), X1 = ld3(sh.vat + 2 * i1), X2 = ld3(sh.vat + 2 * i2);
+      const f3 N0 = ld3(sh.vat + 2 * i0 + 1), N1 = ld3(sh.vat + 2 * i1 + 1), N2 = ld3(sh.vat + 2 * i2 + 1);
+      f3 c0 = sh.objc, c1 = sh.objc, c2 = sh.objc;
+      if (sh.vcol) {
+        c0 = {sh.vcol[3 * i0], sh.vcol[3 * i0 + 1], sh.vcol[3 * i0 + 2]};
+        c1 = {sh.vcol[3 * i1], sh.vcol[3 * i1 + 1], sh.vcol[3 * i1 + 2]};
+        c2 = {sh.vcol[3 * i2], sh.vcol[3 * i2 + 1], sh.vcol[3 * i2 + 2]};
+      }
+      const int cur_pix = pix, cur_face = face;
+      e += MVR_BLOCK;
+      if (e < n_cov) {  // prefetch the next pixel's indices
+        pix = plist[e];
+        face = (int)(unsigned)(keys[pix] & 0xffffffffull);
+        i0 = faces[3 * face]; i1 = faces[3 * face + 1]; i2 = faces[3 * face + 2];
+      }
+      const int row = cur_pix / W, col = cur_pix - row * W;
+      const float px = -1.0f + mvr::div_by(2.0f * (float)(W - 1 - col) + 1.0f, fW, invW);
+      const float py = -1.0f + mvr::div_by(2.0f * (float)(jy_hi - row) + 1.0f, fH, invH);
+      const f3 rgb = shade_fast(P0, P1, P2, px, py, persp, X0, X1, X2, N0, N1, N2, c0, c1, c2, sh);
+      img[cur_pix] = rgb.x; img[HW + cur_pix] = rgb.y; img[2 * HW + cur_pix] = rgb.z;
+      if (p2f) p2f[cur_pix] = cur_face;
+    }
+    if (pend < n_pix) {
+      __syncthreads();
+      if (tid == 0) cnt[0] = 0;
+      __syncthreads();
+    }
   }
   DIAG_STAMP(2);
 }
