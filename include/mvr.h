@@ -44,7 +44,9 @@ enum {
 /* flags for mvr_mesh_params.flags */
 enum {
   MVR_CULL_BACKFACES = 1,      /* RasterizationSettings(cull_backfaces=...), models/renderer.py:98 */
-  MVR_PERSPECTIVE_CORRECT = 2  /* PyTorch3D >=0.5 default for perspective cameras */
+  MVR_PERSPECTIVE_CORRECT = 2, /* PyTorch3D >=0.5 default for perspective cameras */
+  MVR_WORKSPACE_FROM_FORWARD = 4 /* mvr_render_meshes_backward only: `workspace` is the (unmodified) buffer the
+                                    matching mvr_render_meshes_forward call used -> its vertex normals are reused */
 };
 
 /* A batch of B triangle meshes packed back to back (what models/renderer.py:66-77 builds

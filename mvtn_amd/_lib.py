@@ -12,6 +12,7 @@ _vp = ctypes.c_void_p
 MVR_OK = 0
 MVR_CULL_BACKFACES = 1
 MVR_PERSPECTIVE_CORRECT = 2
+MVR_WORKSPACE_FROM_FORWARD = 4
 
 
 class MeshBatch(ctypes.Structure):  # struct mvr_mesh_batch

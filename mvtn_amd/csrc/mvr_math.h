@@ -44,6 +44,25 @@ template <typename T> MVR_HD T div_by(T a, T b, T y) {
   return tfma(r, y, q);
 }
 
+// Reciprocal / reciprocal square root for arithmetic that does NOT decide coverage or depth order (shading
+// colours, gradients): the 1-ulp hardware approximations on the device, exact on the host.
+MVR_HD float trcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+MVR_HD double trcp(double x) { return 1.0 / x; }
+MVR_HD float trsq(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+MVR_HD double trsq(double x) { return 1.0 / sqrt(x); }
+
 template <typename T> struct V3 { T x, y, z; };
 
 template <typename T> MVR_HD V3<T> cross(const V3<T> &a, const V3<T> &b) {
@@ -71,6 +90,20 @@ template <typename T> MVR_HD V3<T> normalize_shared(const V3<T> &v, T eps, T *no
   if (raw_norm) *raw_norm = n;
   T y = (T)1 / d;
   return {div_by(v.x, d, y), div_by(v.y, d, y), div_by(v.z, d, y)};
+}
+
+// v / max(||v||, eps) through one reciprocal square root: inv_d = 1/max(||v||, eps); clamped <=> ||v|| <= eps.
+template <typename T> MVR_HD V3<T> normalize_rs(const V3<T> &v, T eps, T *inv_d, bool *clamped) {
+  T n2 = (v.x * v.x + v.y * v.y) + v.z * v.z;
+  *clamped = !(n2 > eps * eps);
+  T r = trsq(tmax(n2, eps * eps));
+  *inv_d = r;
+  return {v.x * r, v.y * r, v.z * r};
+}
+template <typename T> MVR_HD V3<T> normalize_rs_bwd(const V3<T> &out, T inv_d, bool clamped, const V3<T> &g) {
+  if (clamped) return {g.x * inv_d, g.y * inv_d, g.z * inv_d};
+  T og = dot(out, g);
+  return {(g.x - out.x * og) * inv_d, (g.y - out.y * og) * inv_d, (g.z - out.z * og) * inv_d};
 }
 
 // gradient of normalize: out = v/d, d = max(n, eps).  n > eps: (g - out (out.g))/d ; else g/d.
@@ -354,33 +387,41 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
                                                   const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
                                                   const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
                                                   const V3<T> &G, T acc[18]) {
+  // Gradient arithmetic: no coverage decision depends on it, so quotients go through shared reciprocals
+  // (trcp / trsq) and the compiler may contract multiply-adds.
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
   // ---- forward recompute -------------------------------------------------
   V3<T> Xv0 = world_to_view(cam.R, cam.Tr, X0), Xv1 = world_to_view(cam.R, cam.Tr, X1), Xv2 = world_to_view(cam.R, cam.Tr, X2);
-  T u0 = (cam.s * Xv0.x) / Xv0.z, v0 = (cam.s * Xv0.y) / Xv0.z, z0 = Xv0.z;
-  T u1 = (cam.s * Xv1.x) / Xv1.z, v1 = (cam.s * Xv1.y) / Xv1.z, z1 = Xv1.z;
-  T u2 = (cam.s * Xv2.x) / Xv2.z, v2 = (cam.s * Xv2.y) / Xv2.z, z2 = Xv2.z;
+  const T rz0 = trcp(Xv0.z), rz1 = trcp(Xv1.z), rz2 = trcp(Xv2.z);
+  T u0 = (cam.s * Xv0.x) * rz0, v0 = (cam.s * Xv0.y) * rz0, z0 = Xv0.z;
+  T u1 = (cam.s * Xv1.x) * rz1, v1 = (cam.s * Xv1.y) * rz1, z1 = Xv1.z;
+  T u2 = (cam.s * Xv2.x) * rz2, v2 = (cam.s * Xv2.y) * rz2, z2 = Xv2.z;
   T area = edge_fn(u2, v2, u0, v0, u1, v1) + (T)kEps;
+  const T ra = trcp(area);
   T e0 = edge_fn(px, py, u1, v1, u2, v2), e1 = edge_fn(px, py, u2, v2, u0, v0), e2 = edge_fn(px, py, u0, v0, u1, v1);
-  T a0 = e0 / area, a1 = e1 / area, a2 = e2 / area;
-  T w0 = a0, w1 = a1, w2 = a2, den = (T)1;
+  T a0 = e0 * ra, a1 = e1 * ra, a2 = e2 * ra;
+  T w0 = a0, w1 = a1, w2 = a2, rden = (T)1;
   bool den_clamped = false;
   if (cam.persp) {
     T t0 = (a0 * z1) * z2, t1 = (z0 * a1) * z2, t2 = (z0 * z1) * a2;
     T sum = (t0 + t1) + t2;
-    den = tmax(sum, (T)kEps);
+    rden = trcp(tmax(sum, (T)kEps));
     den_clamped = !(sum > (T)kEps);
-    w0 = t0 / den; w1 = t1 / den; w2 = t2 / den;
+    w0 = t0 * rden; w1 = t1 * rden; w2 = t2 * rden;
   }
   V3<T> p = {(w0 * X0.x + w1 * X1.x) + w2 * X2.x, (w0 * X0.y + w1 * X1.y) + w2 * X2.y, (w0 * X0.z + w1 * X1.z) + w2 * X2.z};
   V3<T> n = {(w0 * N0.x + w1 * N1.x) + w2 * N2.x, (w0 * N0.y + w1 * N1.y) + w2 * N2.y, (w0 * N0.z + w1 * N1.z) + w2 * N2.z};
   V3<T> tex = {(w0 * c0.x + w1 * c1.x) + w2 * c2.x, (w0 * c0.y + w1 * c1.y) + w2 * c2.y, (w0 * c0.z + w1 * c1.z) + w2 * c2.z};
-  T dn, rn, dl, rl, dv, rv;
-  V3<T> nh = normalize_shared(n, (T)kNormalizeEps, &dn, &rn);
-  V3<T> lh = normalize_shared(cam.l, (T)kNormalizeEps, &dl, &rl);
+  T idn, idl, idv;
+  bool cn, cl, cv;
+  V3<T> nh = normalize_rs(n, (T)kNormalizeEps, &idn, &cn);
+  V3<T> lh = normalize_rs(cam.l, (T)kNormalizeEps, &idl, &cl);
   T cosang = dot(nh, lh);
   bool lit = cosang > (T)0;
   V3<T> view = {cam.cc.x - p.x, cam.cc.y - p.y, cam.cc.z - p.z};
-  V3<T> vh = normalize_shared(view, (T)kNormalizeEps, &dv, &rv);
+  V3<T> vh = normalize_rs(view, (T)kNormalizeEps, &idv, &cv);
   V3<T> refl = {-lh.x + (T)2 * (cosang * nh.x), -lh.y + (T)2 * (cosang * nh.y), -lh.z + (T)2 * (cosang * nh.z)};
   T dvr = dot(vh, refl);
   bool spec_on = lit && dvr > (T)0;
@@ -397,8 +438,8 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
     // d(alpha^s)/d alpha = s * alpha^(s-1)
     T dpow;
     if (cam.ph.shininess == (T)64) {
-      T a2 = alpha * alpha, a4 = a2 * a2, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16;
-      dpow = (T)64 * (((a32 * a16) * (a8 * a4)) * (a2 * alpha));
+      T a2_ = alpha * alpha, a4 = a2_ * a2_, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16;
+      dpow = (T)64 * (((a32 * a16) * (a8 * a4)) * (a2_ * alpha));
     } else {
       dpow = cam.ph.shininess * (T)pow((double)alpha, (double)cam.ph.shininess - 1.0);
     }
@@ -408,14 +449,14 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
     g_lh = {-g_r.x, -g_r.y, -g_r.z};
     g_cos += (T)2 * dot(g_r, nh);
     g_nh = {(T)2 * cosang * g_r.x, (T)2 * cosang * g_r.y, (T)2 * cosang * g_r.z};
-    V3<T> g_view = normalize_bwd(vh, dv, !(rv > (T)kNormalizeEps), g_vh);
+    V3<T> g_view = normalize_rs_bwd(vh, idv, cv, g_vh);
     g_cc = g_view;
     g_p = {-g_view.x, -g_view.y, -g_view.z};
   }
   g_nh = {g_nh.x + g_cos * lh.x, g_nh.y + g_cos * lh.y, g_nh.z + g_cos * lh.z};
   g_lh = {g_lh.x + g_cos * nh.x, g_lh.y + g_cos * nh.y, g_lh.z + g_cos * nh.z};
-  V3<T> g_n = normalize_bwd(nh, dn, !(rn > (T)kNormalizeEps), g_nh);
-  V3<T> g_l = normalize_bwd(lh, dl, !(rl > (T)kNormalizeEps), g_lh);
+  V3<T> g_n = normalize_rs_bwd(nh, idn, cn, g_nh);
+  V3<T> g_l = normalize_rs_bwd(lh, idl, cl, g_lh);
   // barycentric gradients
   T gw0 = (dot(g_p, X0) + dot(g_n, N0)) + dot(g_tex, c0);
   T gw1 = (dot(g_p, X1) + dot(g_n, N1)) + dot(g_tex, c1);
@@ -424,17 +465,17 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
   if (cam.persp) {
     T gt0, gt1, gt2;
     if (den_clamped) {
-      gt0 = gw0 / den; gt1 = gw1 / den; gt2 = gw2 / den;
+      gt0 = gw0 * rden; gt1 = gw1 * rden; gt2 = gw2 * rden;
     } else {
       T s_ = (gw0 * w0 + gw1 * w1) + gw2 * w2;
-      gt0 = (gw0 - s_) / den; gt1 = (gw1 - s_) / den; gt2 = (gw2 - s_) / den;
+      gt0 = (gw0 - s_) * rden; gt1 = (gw1 - s_) * rden; gt2 = (gw2 - s_) * rden;
     }
     ga0 = gt0 * (z1 * z2); gz1 += gt0 * (a0 * z2); gz2 += gt0 * (a0 * z1);
     ga1 = gt1 * (z0 * z2); gz0 += gt1 * (a1 * z2); gz2 += gt1 * (z0 * a1);
     ga2 = gt2 * (z0 * z1); gz0 += gt2 * (z1 * a2); gz1 += gt2 * (z0 * a2);
   }
-  T ge0 = ga0 / area, ge1 = ga1 / area, ge2 = ga2 / area;
-  T g_area = -((ga0 * a0 + ga1 * a1) + ga2 * a2) / area;
+  T ge0 = ga0 * ra, ge1 = ga1 * ra, ge2 = ga2 * ra;
+  T g_area = -((ga0 * a0 + ga1 * a1) + ga2 * a2) * ra;
   // edge(p; a, b): d/dax = py - by ; d/day = bx - px ; d/dbx = ay - py ; d/dby = px - ax
   T gu0 = (T)0, gv0 = (T)0, gu1 = (T)0, gv1 = (T)0, gu2 = (T)0, gv2 = (T)0;
   // e0 = edge(p; V1, V2)
@@ -448,17 +489,17 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
   gu0 += g_area * (v2 - v1); gv0 += g_area * (u1 - u2);
   gu1 += g_area * (v0 - v2); gv1 += g_area * (u2 - u0);
   // projection u = s x / z, v = s y / z, zv = z
-  auto proj_bwd = [&](const V3<T> &Xv, T u, T v, T gu, T gv, T gz, const V3<T> &Xw) {
-    T gx = gu * cam.s / Xv.z, gy = gv * cam.s / Xv.z;
-    T gzz = gz - (gu * u + gv * v) / Xv.z;
+  auto proj_bwd = [&](T rz, T u, T v, T gu, T gv, T gz, const V3<T> &Xw) {
+    T gx = gu * cam.s * rz, gy = gv * cam.s * rz;
+    T gzz = gz - (gu * u + gv * v) * rz;
     acc[0] += Xw.x * gx; acc[1] += Xw.x * gy; acc[2] += Xw.x * gzz;
     acc[3] += Xw.y * gx; acc[4] += Xw.y * gy; acc[5] += Xw.y * gzz;
     acc[6] += Xw.z * gx; acc[7] += Xw.z * gy; acc[8] += Xw.z * gzz;
     acc[9] += gx; acc[10] += gy; acc[11] += gzz;
   };
-  proj_bwd(Xv0, u0, v0, gu0, gv0, gz0, X0);
-  proj_bwd(Xv1, u1, v1, gu1, gv1, gz1, X1);
-  proj_bwd(Xv2, u2, v2, gu2, gv2, gz2, X2);
+  proj_bwd(rz0, u0, v0, gu0, gv0, gz0, X0);
+  proj_bwd(rz1, u1, v1, gu1, gv1, gz1, X1);
+  proj_bwd(rz2, u2, v2, gu2, gv2, gz2, X2);
   acc[12] += g_cc.x; acc[13] += g_cc.y; acc[14] += g_cc.z;
   acc[15] += g_l.x; acc[16] += g_l.y; acc[17] += g_l.z;
 }

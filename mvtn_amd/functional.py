@@ -143,24 +143,25 @@ class _RenderMeshes(torch.autograd.Function):
         _lib.check(lib.mvr_render_meshes_forward(mb, params, R.data_ptr(), T.data_ptr(), light.data_ptr(), images.data_ptr(),
                                                  _ptr(p2f), ws.data_ptr(), ws_bytes, _stream()), "mvr_render_meshes_forward")
         if need_grad:
-            ctx.save_for_backward(R, T, light, p2f)
+            ctx.save_for_backward(R, T, light, p2f, ws)  # ws: the backward reuses the vertex attributes in it
             ctx.packed, ctx.params = packed, params
         return images
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
-        R, T, light, p2f = ctx.saved_tensors
+        R, T, light, p2f, ws = ctx.saved_tensors
         packed, params = ctx.packed, ctx.params
         g = _f32c(g)
         N = R.shape[0]
         mb = packed.c_struct()
-        ws_bytes = lib.mvr_mesh_workspace_bytes(mb, params)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=R.device)
+        ws_bytes = ws.numel()
+        bparams = _lib.MeshParams.from_buffer_copy(params)
+        bparams.flags |= _lib.MVR_WORKSPACE_FROM_FORWARD
         gR, gT = torch.empty_like(R), torch.empty_like(T)
         per_view_light = params.n_light == N and N > 0 and ctx.needs_input_grad[2]
         gL = torch.empty(N, 3, dtype=torch.float32, device=R.device) if per_view_light else None
-        _lib.check(lib.mvr_render_meshes_backward(mb, params, R.data_ptr(), T.data_ptr(), light.data_ptr(), p2f.data_ptr(),
+        _lib.check(lib.mvr_render_meshes_backward(mb, bparams, R.data_ptr(), T.data_ptr(), light.data_ptr(), p2f.data_ptr(),
                                                   g.data_ptr(), gR.data_ptr(), gT.data_ptr(), _ptr(gL), ws.data_ptr(), ws_bytes,
                                                   _stream()), "mvr_render_meshes_backward")
         return gR, gT, gL, None, None, None
