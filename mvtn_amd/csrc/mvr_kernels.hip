@@ -1017,9 +1017,11 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_backward_finalize(const floa
 
 struct PointsArgs {
   const float *points, *colors, *R, *T, *dist;
+  const float4 *pv;            // (N, pstride) view-space points (k_points_project)
+  const unsigned short *pbin;  // (N, pstride) row-bin range of each point's disc, 0xFFFF = cannot hit
   float *images;
   int32_t *p2p;
-  int B, P, V, N, H, W, TH, n_strips, views_per_xcd;
+  int B, P, V, N, H, W, TH, n_strips, views_per_xcd, pstride, bin_rows;
   float radius, r2, r2w;
   float obj[3], bg[3];
 };
@@ -1027,6 +1029,33 @@ struct PointsArgs {
 __device__ __forceinline__ f3 point_view(const float *Rm, const float *Tv, float sc, const float *p) {
   f3 xs = {p[0] * sc, p[1] * sc, p[2] * sc};  // Pointclouds.scale_(1/dist), models/renderer.py:142-143
   return mvr::world_to_view<float>(Rm, Tv, xs);
+}
+
+// grid (ceil(P / BLOCK), N): every point is transformed ONCE per view (the rasteriser's strips used to redo it
+// 28 times) and gets the conservative range of row-bins its radius-r disc can reach.
+__global__ void __launch_bounds__(MVR_BLOCK) k_points_project(PointsArgs a, float4 *__restrict__ pv, unsigned short *__restrict__ pbin) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.P) return;
+  const int b = n / a.V;
+  float Rm[9], Tv[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rm[k] = a.R[9 * (size_t)n + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) Tv[k] = a.T[3 * (size_t)n + k];
+  const float sc = 1.0f / a.dist[n];
+  const f3 q = point_view(Rm, Tv, sc, a.points + 3 * ((size_t)b * a.P + p));
+  unsigned short out = MVR_BIN_NONE;
+  if (q.z >= 0.0f && q.x - a.radius <= 1.0f && q.x + a.radius >= -1.0f && q.y - a.radius <= 1.0f && q.y + a.radius >= -1.0f) {
+    int y0, y1;
+    ndc_range(q.y - a.radius, q.y + a.radius, a.H, &y0, &y1);
+    if (y0 <= y1) {
+      int g0 = (a.H - 1 - y1) / a.bin_rows, g1 = (a.H - 1 - y0) / a.bin_rows;
+      out = (unsigned short)(g0 | (g1 << 8));
+    }
+  }
+  pv[(size_t)n * a.pstride + p] = make_float4(q.x, q.y, q.z, 0.f);
+  pbin[(size_t)n * a.pstride + p] = out;
 }
 
 __global__ void __launch_bounds__(MVR_BLOCK) k_points_raster_shade(PointsArgs a) {
@@ -1043,60 +1072,74 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_points_raster_shade(PointsArgs a)
   const int r0 = strip * TH;
   const int rows = min(TH, H - r0);
   const int jy_hi = H - 1 - r0, jy_lo = jy_hi - (rows - 1);
+  const unsigned g_lo = (unsigned)(r0 / a.bin_rows), g_hi = (unsigned)((r0 + rows - 1) / a.bin_rows);
   for (int i = tid; i < rows * W; i += MVR_BLOCK) keys[i] = MVR_KEY_EMPTY;
   for (int i = tid; i < W; i += MVR_BLOCK) px_tab[i] = mvr::pix_to_ndc<float>(i, W);
   for (int i = tid; i < rows; i += MVR_BLOCK) py_tab[i] = mvr::pix_to_ndc<float>(jy_lo + i, H);
   __syncthreads();
-  float Rm[9], Tv[3];
+  const float4 *__restrict__ pv = a.pv + (size_t)n * a.pstride;
+  const unsigned short *__restrict__ pbin = a.pbin + (size_t)n * a.pstride;
+#ifdef MVR_ABL_PTS_NO_SCAN
+  const int P_eff = 0;
+#else
+  const int P_eff = a.P;
+#endif
+  // scan: 4 points (one 8-byte vector of row-bin ranges) per lane; the few that can reach this strip are splatted
+  for (int p0 = tid * 4; p0 < P_eff; p0 += MVR_BLOCK * 4) {
+    const uint2 qb = *reinterpret_cast<const uint2 *>(pbin + p0);
+    const unsigned w[2] = {qb.x, qb.y};
 #pragma unroll
-  for (int k = 0; k < 9; ++k) Rm[k] = a.R[9 * (size_t)n + k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) Tv[k] = a.T[3 * (size_t)n + k];
-  const float sc = 1.0f / a.dist[n];
-  const float *pts = a.points + 3 * (size_t)b * a.P;
-  for (int p = tid; p < a.P; p += MVR_BLOCK) {
-    f3 q = point_view(Rm, Tv, sc, pts + 3 * (size_t)p);
-    if (!(q.z >= 0.0f)) continue;
-    int x0, x1, y0, y1;
-    if (!(q.x - a.radius <= 1.0f && q.x + a.radius >= -1.0f && q.y - a.radius <= 1.0f && q.y + a.radius >= -1.0f)) continue;
-    ndc_range(q.x - a.radius, q.x + a.radius, W, &x0, &x1);
-    ndc_range(q.y - a.radius, q.y + a.radius, H, &y0, &y1);
-    y0 = max(y0, jy_lo); y1 = min(y1, jy_hi);
-    for (int jy = y0; jy <= y1; ++jy) {
-      float dy = q.y - py_tab[jy - jy_lo];
-      unsigned long long *krow = keys + (size_t)(jy_hi - jy) * W + (W - 1);
-      for (int ix = x0; ix <= x1; ++ix) {
-        float dx = q.x - px_tab[ix];
-        float dd = dx * dx + dy * dy;
-        if (dd < a.r2) {
-          unsigned long long key = ((unsigned long long)__float_as_uint(q.z + 0.0f) << 32) | (unsigned)p;
-          atomicMin(krow - ix, key);
+    for (int k = 0; k < 4; ++k) {
+      const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+      const int p = p0 + k;
+      if (e == MVR_BIN_NONE || (e & 0xffu) > g_hi || (e >> 8) < g_lo || p >= a.P) continue;
+      const float4 q = pv[p];
+      int x0, x1, y0, y1;
+      ndc_range(q.x - a.radius, q.x + a.radius, W, &x0, &x1);
+      ndc_range(q.y - a.radius, q.y + a.radius, H, &y0, &y1);
+      y0 = max(y0, jy_lo); y1 = min(y1, jy_hi);
+      for (int jy = y0; jy <= y1; ++jy) {
+        const float dy = q.y - py_tab[jy - jy_lo];
+        unsigned long long *krow = keys + (size_t)(jy_hi - jy) * W + (W - 1);
+        for (int ix = x0; ix <= x1; ++ix) {
+          const float dx = q.x - px_tab[ix];
+          const float dd = dx * dx + dy * dy;
+          if (dd < a.r2) {
+            unsigned long long key = ((unsigned long long)__float_as_uint(q.z + 0.0f) << 32) | (unsigned)p;
+            atomicMin(krow - ix, key);
+          }
         }
       }
     }
   }
   __syncthreads();
   const size_t HW = (size_t)H * W;
-  float *img = a.images + (size_t)n * 3 * HW + (size_t)r0 * W;
-  int32_t *p2p = a.p2p ? a.p2p + (size_t)n * HW + (size_t)r0 * W : nullptr;
-  const float *cols = a.colors ? a.colors + 3 * (size_t)b * a.P : nullptr;
-  for (int pix = tid; pix < rows * W; pix += MVR_BLOCK) {
-    unsigned long long key = keys[pix];
+  float *__restrict__ img = a.images + (size_t)n * 3 * HW + (size_t)r0 * W;
+  int32_t *__restrict__ p2p = a.p2p ? a.p2p + (size_t)n * HW + (size_t)r0 * W : nullptr;
+  const float *__restrict__ cols = a.colors ? a.colors + 3 * (size_t)b * a.P : nullptr;
+  int row = tid / W, col = tid - row * W;
+  const int drow = MVR_BLOCK / W, dcol = MVR_BLOCK - drow * W;
+  for (int pix = tid; pix < rows * W; pix += MVR_BLOCK, row += drow, col += dcol) {
+    if (col >= W) { col -= W; ++row; }
+    const unsigned long long key = keys[pix];
     float cr = a.bg[0], cg = a.bg[1], cb = a.bg[2];
     int pi = -1;
     if (key != MVR_KEY_EMPTY) {
       pi = (int)(unsigned)(key & 0xffffffffull);
-      int row = pix / W, col = pix - row * W;
-      f3 q = point_view(Rm, Tv, sc, pts + 3 * (size_t)pi);
-      float dx = q.x - px_tab[W - 1 - col], dy = q.y - py_tab[jy_hi - row - jy_lo];
-      float dd = dx * dx + dy * dy;
-      float w = 1.0f - dd / a.r2w;
-      float cum = w < 1e-4f ? 1e-4f : w;  // NormWeightedCompositor kEpsilon clamp
+      const float4 q = pv[pi];
+      const float dx = q.x - px_tab[W - 1 - col], dy = q.y - py_tab[jy_hi - row - jy_lo];
+      const float dd = dx * dx + dy * dy;
+      const float w = 1.0f - dd / a.r2w;
+      const float cum = w < 1e-4f ? 1e-4f : w;  // NormWeightedCompositor kEpsilon clamp
       float f0 = a.obj[0], f1 = a.obj[1], f2 = a.obj[2];
       if (cols) { f0 = cols[3 * (size_t)pi]; f1 = cols[3 * (size_t)pi + 1]; f2 = cols[3 * (size_t)pi + 2]; }
       cr = (f0 * w) / cum; cg = (f1 * w) / cum; cb = (f2 * w) / cum;
     }
+#ifdef MVR_ABL_PTS_NO_STORE
+    if (cr == 123.f) img[pix] = cr;
+#else
     img[pix] = cr; img[HW + pix] = cg; img[2 * HW + pix] = cb;
+#endif
     if (p2p) p2p[pix] = pi;
   }
 }
@@ -1453,14 +1496,36 @@ int mvr_render_meshes_backward(const mvr_mesh_batch *meshes, const mvr_mesh_para
 }
 
 static int points_strip_rows(const mvr_points_params *p) {
-  return p->strip_rows > 0 ? p->strip_rows : default_strip_rows(p->image_h, p->image_w);
+  if (p->strip_rows > 0) return p->strip_rows;
+  int th = 2 * default_strip_rows(p->image_h, p->image_w);   // few LDS bytes besides the keys: taller strips pay (measured)
+  return th > p->image_h ? p->image_h : th;
+}
+
+struct PointsWs {
+  float4 *pv;            // N * pstride
+  unsigned short *pbin;  // N * pstride
+  float *partials;       // N * n_strips * 13
+  int pstride;
+  size_t bytes;
+};
+
+static PointsWs points_ws_layout(const mvr_points_params *p, void *base) {
+  PointsWs w;
+  int TH = points_strip_rows(p);
+  int n_strips = (p->image_h + TH - 1) / TH;
+  size_t N = (size_t)p->n_clouds * p->n_views;
+  w.pstride = (int)align_up((size_t)p->n_points, 8);
+  size_t off = 0;
+  w.pv = (float4 *)((char *)base + off); off += align_up(N * w.pstride * sizeof(float4), 256);
+  w.pbin = (unsigned short *)((char *)base + off); off += align_up(N * w.pstride * sizeof(unsigned short), 256);
+  w.partials = (float *)((char *)base + off); off += align_up(N * n_strips * MVR_PACC * sizeof(float), 256);
+  w.bytes = off;
+  return w;
 }
 
 size_t mvr_points_workspace_bytes(const mvr_points_params *p) {
   if (!p) return 0;
-  int TH = points_strip_rows(p);
-  int n_strips = (p->image_h + TH - 1) / TH;
-  return align_up((size_t)p->n_clouds * p->n_views * n_strips * MVR_PACC * sizeof(float), 256);
+  return points_ws_layout(p, nullptr).bytes;
 }
 
 static int check_points_args(const mvr_points_params *p) {
@@ -1475,16 +1540,23 @@ static int check_points_args(const mvr_points_params *p) {
 int mvr_render_points_forward(const mvr_points_params *p, const float *points, const float *point_colors, const float *R,
                               const float *T, const float *dist, float *images, int32_t *pix_to_point, void *workspace,
                               size_t workspace_bytes, mvr_stream_t stream) {
-  (void)workspace; (void)workspace_bytes;
   int rc = check_points_args(p);
   if (rc != MVR_OK) return rc;
-  if (!points || !R || !T || !dist || !images) return set_err(MVR_ERR_INVALID_ARG, "mvr_render_points_forward: null pointer");
+  if (!points || !R || !T || !dist || !images || !workspace)
+    return set_err(MVR_ERR_INVALID_ARG, "mvr_render_points_forward: null pointer");
+  PointsWs ws = points_ws_layout(p, workspace);
+  if (workspace_bytes < ws.bytes) return set_err(MVR_ERR_WORKSPACE, "mvr_render_points_forward: workspace too small");
   PointsArgs a;
+  a.pv = ws.pv; a.pbin = ws.pbin; a.pstride = ws.pstride;
   a.points = points; a.colors = point_colors; a.R = R; a.T = T; a.dist = dist; a.images = images; a.p2p = pix_to_point;
   a.B = p->n_clouds; a.P = p->n_points; a.V = p->n_views; a.N = a.B * a.V; a.H = p->image_h; a.W = p->image_w;
   a.TH = points_strip_rows(p); a.n_strips = (a.H + a.TH - 1) / a.TH; a.views_per_xcd = (a.N + 7) / 8;
   a.radius = (float)p->radius; a.r2 = a.radius * a.radius; a.r2w = (float)(p->radius * p->radius);
   for (int k = 0; k < 3; ++k) { a.obj[k] = p->obj_color[k]; a.bg[k] = p->bg_color[k]; }
+  a.bin_rows = bin_rows_for(a.H, a.TH);
+  hipLaunchKernelGGL(k_points_project, dim3((a.P + MVR_BLOCK - 1) / MVR_BLOCK, a.N), dim3(MVR_BLOCK), 0, (hipStream_t)stream, a,
+                     ws.pv, ws.pbin);
+  HIP_TRY(hipGetLastError());
   size_t lds = (size_t)a.TH * a.W * 8 + (size_t)(a.W + a.TH) * 4 + 16;
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
   if (lds > 64 * 1024)
@@ -1508,7 +1580,7 @@ int mvr_render_points_backward(const mvr_points_params *p, const float *points, 
   if (workspace_bytes < mvr_points_workspace_bytes(p)) return set_err(MVR_ERR_WORKSPACE, "mvr_render_points_backward: workspace too small");
   PointsBwdArgs a;
   a.points = points; a.colors = point_colors; a.R = R; a.T = T; a.dist = dist; a.gimg = grad_images; a.p2p = pix_to_point;
-  a.partials = (float *)workspace;
+  a.partials = points_ws_layout(p, workspace).partials;
   a.B = p->n_clouds; a.P = p->n_points; a.V = p->n_views; a.N = a.B * a.V; a.H = p->image_h; a.W = p->image_w;
   a.TH = points_strip_rows(p); a.n_strips = (a.H + a.TH - 1) / a.TH; a.views_per_xcd = (a.N + 7) / 8;
   a.r2w = (float)(p->radius * p->radius);

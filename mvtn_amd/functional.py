@@ -197,8 +197,10 @@ def render_points_fragments(points, colors, R, T, dist, params):
     B, V, H, W = params.n_clouds, params.n_views, params.image_h, params.image_w
     images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=R.device)
     p2p = torch.empty(B * V, H, W, dtype=torch.int32, device=R.device)
+    ws_bytes = lib.mvr_points_workspace_bytes(params)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=R.device)
     _lib.check(lib.mvr_render_points_forward(params, points.data_ptr(), _ptr(colors), R.data_ptr(), T.data_ptr(),
-                                             dist.data_ptr(), images.data_ptr(), p2p.data_ptr(), None, 0, _stream()),
+                                             dist.data_ptr(), images.data_ptr(), p2p.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
                "mvr_render_points_forward")
     return images, p2p
 
@@ -239,8 +241,10 @@ class _RenderPoints(torch.autograd.Function):
             raise ValueError("R/T/dist must have B*V = %d rows" % N)
         images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=R.device)
         p2p = torch.empty(N, H, W, dtype=torch.int32, device=R.device) if need_grad else None
+        ws_bytes = lib.mvr_points_workspace_bytes(params)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=R.device)
         _lib.check(lib.mvr_render_points_forward(params, points.data_ptr(), _ptr(colors), R.data_ptr(), T.data_ptr(),
-                                                 dist.data_ptr(), images.data_ptr(), _ptr(p2p), None, 0, _stream()),
+                                                 dist.data_ptr(), images.data_ptr(), _ptr(p2p), ws.data_ptr(), ws_bytes, _stream()),
                    "mvr_render_points_forward")
         if need_grad:
             ctx.save_for_backward(R, T, dist, points, p2p)
