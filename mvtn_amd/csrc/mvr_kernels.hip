@@ -36,8 +36,7 @@ typedef V3<float> f3;
 #define MVR_WAVES (MVR_BLOCK / 64)
 #define MVR_SCAN_PER_LANE 4     // faces per lane per scan round (one 8-byte vector of 2-byte row-bin ranges)
 #define MVR_LIST_CAP 1536       // LDS face list (4 B entries): flushed before a worst-case scan round (1024) could overflow it
-#define MVR_BATCH 160           // faces set up / rasterised per batch (one per lane in the setup phase; <= 256)
-#define MVR_WQ_CAP 128          // per-wave survivor stack (ints): < 64 carried over + <= 64 pushed per iteration
+#define MVR_BATCH 256           // faces set up / rasterised per batch (one per lane in the setup phase)
 #define MVR_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define MVR_NACC 18
 
@@ -481,40 +480,6 @@ __device__ __forceinline__ void unpack_face(const FaceCoef &q, mvr::FaceSetup<fl
   fs.drawable = true;
 }
 
-// Coarse (conservative) linear form of one edge function for the rasteriser's first pass.
-// Exact form (mvr::edge_fn, pre-multiplied by sgn = sign(area) so that "inside" means > 0):
-//   e(px,py) = sgn * ((px - a.x) (b.y - a.y) - (py - a.y) (b.x - a.x)),   px = -1 + (2 ix + 1)/W, py likewise.
-// In pixel-index space e = A ix + B jy + C.  The coarse pass evaluates it with running sums whose rounding error
-// is < (1e-5 + 6e-8 W) M, M bounding the magnitude of the products in both forms; adding
-// (1e-4 + 1e-6 W) M to C makes "coarse > 0" a SUPERSET of "exact float test > 0": a false positive only costs
-// an exact re-test, a false negative cannot happen.
-__device__ __forceinline__ void coarse_edge(const f3 &a, const f3 &b, float sgn, float fW, float fH, float invW, float invH,
-                                            float *A, float *B, float *C) {
-#pragma clang fp contract(fast)
-  const float dY = b.y - a.y, dX = b.x - a.x;
-  const float An = sgn * dY, Bn = -sgn * dX, Cn = sgn * (dX * a.y - dY * a.x);   // e = An px + Bn py + Cn
-  const float M = fabsf(dY) * (1.0f + fabsf(a.x)) + fabsf(dX) * (1.0f + fabsf(a.y));
-  *A = 2.0f * An * invW;
-  *B = 2.0f * Bn * invH;
-  *C = Cn + An * (invW - 1.0f) + Bn * (invH - 1.0f) + (1e-4f + 1e-6f * fmaxf(fW, fH)) * M;
-}
-
-// Exact pass on one stacked candidate: unpack (batch entry, ix, jy), exact IEEE face test, depth update.
-__device__ __forceinline__ void exact_candidate(unsigned ent, const FaceCoef *coef, unsigned long long *keys, int W, int jy_lo,
-                                                int jy_hi, float fW, float fH, float invW, float invH, bool persp) {
-  const int e = (int)(ent & 0xffu), ix = (int)((ent >> 8) & 0x7fffu), jy = jy_lo + (int)(ent >> 23);
-  mvr::FaceSetup<float> fs;
-  int f;
-  unpack_face(coef[e], fs, f);
-  const float px = -1.0f + mvr::div_by(2.0f * (float)ix + 1.0f, fW, invW);
-  const float py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);
-  float pz, w0, w1, w2;
-  if (mvr::face_test<float>(fs, px, py, persp, &pz, &w0, &w1, &w2)) {
-    unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
-    atomicMin(keys + (size_t)(jy_hi - jy) * W + (W - 1 - ix), key);
-  }
-}
-
 // One workgroup per (view, strip of TH image rows).
 //   scan     : 2-byte row-bin ranges of the view's faces (k_face_bins) -> LDS list of faces touching the strip
 //   setup    : one lane per listed face: gather its 3 projected vertices, exact candidate range, coefficient
@@ -528,11 +493,10 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
   extern __shared__ __align__(16) unsigned char smem[];
   const int W = a.W, H = a.H, TH = a.TH;
   unsigned long long *keys = (unsigned long long *)smem;                       // TH * W
-  FaceCoef *coef = (FaceCoef *)(keys + (size_t)TH * W);                        // MVR_BATCH exact records
-  FaceCoef *apx = coef + MVR_BATCH;                                            // MVR_BATCH coarse records (+ ranges)
-  int *cum = (int *)(apx + MVR_BATCH);                                         // MVR_BLOCK + 1 exclusive prefix sums
-  int *wqueue = cum + (MVR_BLOCK + 1);                                         // MVR_WAVES x MVR_WQ_CAP survivor stacks
-  int *list = wqueue + MVR_WAVES * MVR_WQ_CAP;                                 // MVR_LIST_CAP face indices
+  FaceCoef *coef = (FaceCoef *)(keys + (size_t)TH * W);                        // MVR_BATCH
+  int2 *rng = (int2 *)(coef + MVR_BATCH);                                      // MVR_BATCH: x0|x1<<16 , y0|y1<<16
+  int *cum = (int *)(rng + MVR_BATCH);                                         // MVR_BATCH + 1 exclusive prefix sums
+  int *list = cum + (MVR_BATCH + 1);                                           // MVR_LIST_CAP face indices
   int *cnt = list + MVR_LIST_CAP;                                              // [0] list entries, [1..4] wave totals
 
   int n, strip;
@@ -605,13 +569,8 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
     unsigned long long tc1 = clock64();
     t_scan += tc1 - tc0; n_small_tot += n_list;
 #endif
-#ifdef MVR_ABL_NO_RASTER
-    if (n_list >= 0) { if (!last) { __syncthreads(); if (tid == 0) cnt[0] = 0; __syncthreads(); } continue; }
-#endif
-    const int n_batches = (n_list + MVR_BATCH - 1) / MVR_BATCH;
-    const int batch_len = n_batches ? (n_list + n_batches - 1) / n_batches : 0;   // even split, <= MVR_BATCH
-    for (int b0 = 0; b0 < n_list; b0 += batch_len) {
-      const int nb = min(batch_len, n_list - b0);
+    for (int b0 = 0; b0 < n_list; b0 += MVR_BATCH) {
+      const int nb = min(MVR_BATCH, n_list - b0);
 #ifdef MVR_DIAG
       unsigned long long ts0 = clock64();
 #endif
@@ -627,17 +586,7 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
         q.b = make_float4(fs.v1.y, fs.v1.z, fs.v2.x, fs.v2.y);
         q.c = make_float4(fs.v2.z, fs.area, fs.inv_area, __int_as_float(f));
         coef[tid] = q;
-        // conservative linear edge functions in pixel-index space for the coarse pass (see coarse_edge)
-        const float sgn = fs.area > 0.0f ? 1.0f : -1.0f;
-        float A0, B0, C0, A1, B1, C1, A2, B2, C2;
-        coarse_edge(fs.v1, fs.v2, sgn, fW, fH, invW, invH, &A0, &B0, &C0);
-        coarse_edge(fs.v2, fs.v0, sgn, fW, fH, invW, invH, &A1, &B1, &C1);
-        coarse_edge(fs.v0, fs.v1, sgn, fW, fH, invW, invH, &A2, &B2, &C2);
-        FaceCoef g;
-        g.a = make_float4(A0, B0, C0, A1);
-        g.b = make_float4(B1, C1, A2, B2);
-        g.c = make_float4(C2, __int_as_float(x0 | (x1 << 16)), __int_as_float(y0 | (y1 << 16)), 0.0f);
-        apx[tid] = g;
+        rng[tid] = make_int2(x0 | (x1 << 16), y0 | (y1 << 16));
       }
       // workgroup exclusive prefix sum of the candidate counts
       int incl = my_cnt;
@@ -656,91 +605,60 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
         total += t;
       }
       cum[tid] = wave_off + incl - my_cnt;
-      if (tid == 0) cum[MVR_BLOCK] = total;
+      if (tid == 0) cum[MVR_BATCH] = total;
       __syncthreads();
 #ifdef MVR_DIAG
       unsigned long long ts1 = clock64();
       t_small += ts1 - ts0; n_large_tot += total;
 #endif
       // ---- raster: balanced split of the batch's `total` (face, pixel) candidates over 256 lanes -------
-      //  coarse pass (R1): every candidate is classified with 3 adds + min3 on the conservative linear edge
-      //  functions; survivors (true inside pixels + a ~1e-4-wide band around the edges) are pushed on a small
-      //  per-wave LDS stack;  exact pass (R2): whenever 64 survivors are stacked the whole wave pops them and
-      //  runs the exact IEEE test + depth update with every lane busy.
-#ifdef MVR_ABL_NO_PIXELS
-      const int quota = 0;
-#else
       const int quota = (total + MVR_BLOCK - 1) / MVR_BLOCK;
-#endif
       const int p0 = tid * quota;
-      const int rem = max(0, min(quota, total - p0));
-      int e = 0, ix = 0, jy = 0, left = 0, x0 = 0, x1 = 0;
-      float A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, B2 = 0, E0 = 0, E1 = 0, E2 = 0, R0 = 0, R1 = 0, R2 = 0;
+      int rem = min(quota, total - p0);
       if (rem > 0) {
-        int lo = 0, hi = MVR_BLOCK;  // invariant: cum[lo] <= p0 < cum[hi]
+        // e = last entry with cum[e] <= p0  (upper_bound - 1); entries with zero candidates are skipped by it
+        int lo = 0, hi = MVR_BATCH;  // invariant: cum[lo] <= p0 < cum[hi]
         while (hi - lo > 1) {
           int mid = (lo + hi) >> 1;
           if (cum[mid] <= p0) lo = mid; else hi = mid;
         }
-        e = lo;
-        const FaceCoef g = apx[e];
-        const int xr = __float_as_int(g.c.y), yr = __float_as_int(g.c.z);
-        x0 = xr & 0xffff; x1 = xr >> 16;
-        const int y0 = yr & 0xffff, y1 = yr >> 16;
-        const int bw = x1 - x0 + 1;
-        const int o = p0 - cum[e];
-        const int dy = o / bw;
-        jy = y0 + dy; ix = x0 + (o - dy * bw);
-        left = bw * (y1 - y0 + 1) - o;
-        A0 = g.a.x; B0 = g.a.y; A1 = g.a.w; B1 = g.b.x; A2 = g.b.z; B2 = g.b.w;
-        R0 = A0 * (float)x0 + (B0 * (float)jy + g.a.z);
-        R1 = A1 * (float)x0 + (B1 * (float)jy + g.b.y);
-        R2 = A2 * (float)x0 + (B2 * (float)jy + g.c.x);
-        const float dx = (float)(ix - x0);
-        E0 = R0 + A0 * dx; E1 = R1 + A1 * dx; E2 = R2 + A2 * dx;
-      }
-      int *wq = wqueue + wave * MVR_WQ_CAP;
-      int qn = 0;  // wave-uniform stack height
-      const unsigned long long below = (1ull << lane) - 1ull;
-      for (int it = 0; it < quota; ++it) {
-        bool cand = false;
-        unsigned ent = 0;
-        if (it < rem) {
-          if (left == 0) {   // next face with candidates (exists: this lane still has quota)
-            do { ++e; } while (cum[e + 1] == cum[e]);
-            const FaceCoef g = apx[e];
-            const int xr = __float_as_int(g.c.y), yr = __float_as_int(g.c.z);
-            x0 = xr & 0xffff; x1 = xr >> 16;
-            const int y0 = yr & 0xffff, y1 = yr >> 16;
+        int e = lo;
+        mvr::FaceSetup<float> fs;
+        int f, x0, x1, y0, y1, ix, jy, left;
+        {
+          unpack_face(coef[e], fs, f);
+          const int2 r = rng[e];
+          x0 = r.x & 0xffff; x1 = r.x >> 16; y0 = r.y & 0xffff; y1 = r.y >> 16;
+          const int bw = x1 - x0 + 1;
+          const int o = p0 - cum[e];
+          const int dy = o / bw;
+          jy = y0 + dy; ix = x0 + (o - dy * bw);
+          left = bw * (y1 - y0 + 1) - o;
+        }
+        float py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);
+        while (true) {
+          const float px = -1.0f + mvr::div_by(2.0f * (float)ix + 1.0f, fW, invW);
+          float pz, w0, w1, w2;
+          if (mvr::face_test<float>(fs, px, py, persp, &pz, &w0, &w1, &w2)) {
+            unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
+            atomicMin(keys + (size_t)(jy_hi - jy) * W + (W - 1 - ix), key);
+          }
+          if (--rem == 0) break;
+          if (--left == 0) {
+            do { ++e; } while (cum[e + 1] == cum[e]);   // next face with candidates (exists: rem > 0)
+            unpack_face(coef[e], fs, f);
+            const int2 r = rng[e];
+            x0 = r.x & 0xffff; x1 = r.x >> 16; y0 = r.y & 0xffff; y1 = r.y >> 16;
             left = (x1 - x0 + 1) * (y1 - y0 + 1);
             ix = x0; jy = y0;
-            A0 = g.a.x; B0 = g.a.y; A1 = g.a.w; B1 = g.b.x; A2 = g.b.z; B2 = g.b.w;
-            R0 = A0 * (float)x0 + (B0 * (float)jy + g.a.z);
-            R1 = A1 * (float)x0 + (B1 * (float)jy + g.b.y);
-            R2 = A2 * (float)x0 + (B2 * (float)jy + g.c.x);
-            E0 = R0; E1 = R1; E2 = R2;
+            py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);
+          } else if (++ix > x1) {
+            ix = x0; ++jy;
+            py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);
           }
-          cand = fminf(fminf(E0, E1), E2) > 0.0f;
-          ent = (unsigned)e | ((unsigned)ix << 8) | ((unsigned)(jy - jy_lo) << 23);
-          --left;
-          if (++ix > x1) { ix = x0; ++jy; R0 += B0; R1 += B1; R2 += B2; E0 = R0; E1 = R1; E2 = R2; }
-          else { E0 += A0; E1 += A1; E2 += A2; }
-        }
-        const unsigned long long mc = __ballot(cand);
-        if (mc) {
-          if (cand) wq[qn + __popcll(mc & below)] = (int)ent;
-          qn += __popcll(mc);
-        }
-        if (qn >= 64) {   // wave-uniform
-          qn -= 64;
-          __builtin_amdgcn_wave_barrier();
-          exact_candidate((unsigned)wq[qn + lane], coef, keys, W, jy_lo, jy_hi, fW, fH, invW, invH, persp);
-          __builtin_amdgcn_wave_barrier();
         }
       }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < qn) exact_candidate((unsigned)wq[lane], coef, keys, W, jy_lo, jy_hi, fW, fH, invW, invH, persp);
-      __syncthreads();   // coef / apx / cum are rewritten by the next batch; keys are complete for this one
+      __syncthreads();   // coef / rng / cum are rewritten by the next batch; keys are complete for this one
 #ifdef MVR_DIAG
       t_large += clock64() - ts1;
 #endif
@@ -784,7 +702,7 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
   }
 
   int *plist = (int *)coef;                       // the batch records are dead now: reuse their LDS
-  const int plist_cap = (int)(2 * sizeof(FaceCoef) * MVR_BATCH / sizeof(int));
+  const int plist_cap = (int)((sizeof(FaceCoef) + sizeof(int2)) * MVR_BATCH / sizeof(int));
   const int n_pix = rows * W;
   if (tid == 0) cnt[0] = 0;
   __syncthreads();
@@ -808,11 +726,7 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
       }
     }
     __syncthreads();
-#ifdef MVR_ABL_NO_SHADE
-    const int n_cov = 0;
-#else
     const int n_cov = cnt[0];
-#endif
     // ---- shade the covered pixels (dense).  Software-pipelined: the index chain of the NEXT pixel
     //      (LDS list -> LDS key -> face's vertex indices from L2) is issued before the current pixel's
     //      9 attribute gathers are consumed, so the two dependent latencies overlap. ------------------------
@@ -1439,9 +1353,8 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   a.n_light = params->n_light; a.flags = params->flags; a.s = s;
   a.ambient = params->ambient; a.diffuse = params->diffuse; a.specular = params->specular; a.shininess = params->shininess;
   for (int k = 0; k < 3; ++k) { a.obj[k] = params->obj_color[k]; a.bg[k] = params->bg_color[k]; }
-  if (TH > 512) return set_err(MVR_ERR_UNSUPPORTED, "strip_rows > 512");
-  size_t lds = (size_t)TH * W * 8 + (size_t)MVR_BATCH * 2 * sizeof(FaceCoef) + (size_t)(MVR_BLOCK + 1) * 4 +
-               (size_t)MVR_WAVES * MVR_WQ_CAP * 4 + (size_t)MVR_LIST_CAP * 4 + 8 * 4;
+  size_t lds = (size_t)TH * W * 8 + (size_t)MVR_BATCH * (sizeof(FaceCoef) + sizeof(int2)) + (size_t)(MVR_BATCH + 1) * 4 +
+               (size_t)MVR_LIST_CAP * 4 + 8 * 4;
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_raster_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
