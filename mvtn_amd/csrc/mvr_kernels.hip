@@ -226,11 +226,9 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_normals_accum(MeshPtrs m, long lo
 // atomics; same fixed-point sum as the 3-step global path, hence the same bits.
 #define MVR_NRM_BLOCK 1024
 #define MVR_NRM_LDS_VERTS 6400   // 6400 * 24 B = 150 KiB
-__global__ void __launch_bounds__(MVR_NRM_BLOCK) k_vattr_mesh_lds(MeshPtrs m, float4 *__restrict__ vattr,
-                                                                  float *__restrict__ normals_out) {
-  extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void vattr_mesh_lds_body(const MeshPtrs &m, int b, unsigned char *smem, float4 *__restrict__ vattr,
+                                                    float *__restrict__ normals_out) {
   unsigned long long *acc = (unsigned long long *)smem;
-  const int b = blockIdx.x;
   const int f0 = m.face_off[b], nf = m.face_off[b + 1] - f0, v0 = m.vert_off[b], nv = m.vert_off[b + 1] - v0;
   for (int i = threadIdx.x; i < 3 * nv; i += MVR_NRM_BLOCK) acc[i] = 0ull;
   __syncthreads();
@@ -260,6 +258,12 @@ __global__ void __launch_bounds__(MVR_NRM_BLOCK) k_vattr_mesh_lds(MeshPtrs m, fl
     vattr[2 * v + 1] = make_float4(n.x, n.y, n.z, 0.f);
     if (normals_out) { normals_out[3 * v] = n.x; normals_out[3 * v + 1] = n.y; normals_out[3 * v + 2] = n.z; }
   }
+}
+
+__global__ void __launch_bounds__(MVR_NRM_BLOCK) k_vattr_mesh_lds(MeshPtrs m, float4 *__restrict__ vattr,
+                                                                  float *__restrict__ normals_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  vattr_mesh_lds_body(m, blockIdx.x, smem, vattr, normals_out);
 }
 
 // one lane per vertex: normalise the accumulated normal (eps 1e-6) and store the position beside it.
@@ -341,6 +345,31 @@ __device__ __forceinline__ void ndc_range(float lo, float hi, int S, int *i0, in
 
 #define MVR_BIN_NONE 0xFFFFu   // face can touch no pixel of this view (culled / off-screen)
 
+// Row-bin range (g0 | g1 << 8) of one projected face, MVR_BIN_NONE if it can touch no pixel: the per-face culls of
+// mvr::face_setup (without its reciprocal) + the conservative pixel range of its bounding box.
+__device__ __forceinline__ unsigned short face_bin_range(const f3 &v0, const f3 &v1, const f3 &v2, int H, int W, int G,
+                                                         int cull_backfaces, float px_lo, float px_hi, float py_lo, float py_hi) {
+  const float xmin = fminf(fminf(v0.x, v1.x), v2.x), xmax = fmaxf(fmaxf(v0.x, v1.x), v2.x);
+  const float ymin = fminf(fminf(v0.y, v1.y), v2.y), ymax = fmaxf(fmaxf(v0.y, v1.y), v2.y);
+  const float zmin = fminf(fminf(v0.z, v1.z), v2.z), zmax = fmaxf(fmaxf(v0.z, v1.z), v2.z);
+  const float face_area = mvr::edge_fn(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+  const bool zero_area = (face_area <= mvr::kEps && face_area >= -mvr::kEps);
+  bool ok = !(zmax < 0.f || (cull_backfaces && face_area < 0.f) || zmin < mvr::kEps || zero_area);
+  // NaN coordinates fail every comparison below -> not drawable (the exact test would reject every pixel too)
+  ok = ok && xmax >= px_lo && xmin <= px_hi && ymax >= py_lo && ymin <= py_hi;
+  unsigned short out = MVR_BIN_NONE;
+  if (ok) {
+    int x0, x1, y0, y1;
+    ndc_range(xmin, xmax, W, &x0, &x1);
+    ndc_range(ymin, ymax, H, &y0, &y1);
+    if (x0 <= x1 && y0 <= y1) {
+      int g0 = (H - 1 - y1) / G, g1 = (H - 1 - y0) / G;  // NDC row index jy <-> image row H-1-jy
+      out = (unsigned short)(g0 | (g1 << 8));
+    }
+  }
+  return out;
+}
+
 // grid (ceil(max_faces / BLOCK), N).  bins[n * stride + f] = g0 | (g1 << 8): first / last row-bin (G image rows
 // each, G a multiple of the strip height chosen so that there are <= 254 bins) that the face's bounding box
 // can reach; conservative (ndc_range).  Rows of the table are padded to `stride` (multiple of 8) entries so
@@ -357,27 +386,69 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_face_bins(MeshPtrs m, int V, int 
   const float4 *__restrict__ proj = proj_all + (size_t)V * vo + (size_t)v * nv;
   const int32_t *__restrict__ fc = m.faces + 3 * (size_t)(fo + f);
   const f3 v0 = ld3(proj + fc[0]), v1 = ld3(proj + fc[1]), v2 = ld3(proj + fc[2]);
-  // the per-face culls of mvr::face_setup (without its reciprocal)
-  const float xmin = fminf(fminf(v0.x, v1.x), v2.x), xmax = fmaxf(fmaxf(v0.x, v1.x), v2.x);
-  const float ymin = fminf(fminf(v0.y, v1.y), v2.y), ymax = fmaxf(fmaxf(v0.y, v1.y), v2.y);
-  const float zmin = fminf(fminf(v0.z, v1.z), v2.z), zmax = fmaxf(fmaxf(v0.z, v1.z), v2.z);
-  const float face_area = mvr::edge_fn(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
-  const bool zero_area = (face_area <= mvr::kEps && face_area >= -mvr::kEps);
-  bool ok = !(zmax < 0.f || (cull_backfaces && face_area < 0.f) || zmin < mvr::kEps || zero_area);
-  // NaN coordinates fail every comparison below -> not drawable (the exact test would reject every pixel too)
-  ok = ok && xmax >= mvr::pix_to_ndc<float>(0, W) && xmin <= mvr::pix_to_ndc<float>(W - 1, W) &&
-       ymax >= mvr::pix_to_ndc<float>(0, H) && ymin <= mvr::pix_to_ndc<float>(H - 1, H);
-  unsigned short out = MVR_BIN_NONE;
-  if (ok) {
-    int x0, x1, y0, y1;
-    ndc_range(xmin, xmax, W, &x0, &x1);
-    ndc_range(ymin, ymax, H, &y0, &y1);
-    if (x0 <= x1 && y0 <= y1) {
-      int g0 = (H - 1 - y1) / G, g1 = (H - 1 - y0) / G;  // NDC row index jy <-> image row H-1-jy
-      out = (unsigned short)(g0 | (g1 << 8));
-    }
-  }
+  const unsigned short out = face_bin_range(v0, v1, v2, H, W, G, cull_backfaces, mvr::pix_to_ndc<float>(0, W),
+                                            mvr::pix_to_ndc<float>(W - 1, W), mvr::pix_to_ndc<float>(0, H),
+                                            mvr::pix_to_ndc<float>(H - 1, H));
   bins[(size_t)n * stride + f] = out;
+}
+
+// One 1024-thread workgroup per VIEW when the mesh's projected vertices fit in LDS (12 B each): project every
+// vertex (-> LDS and the global `proj` table the rasteriser gathers from), barrier, then the per-face row-bin
+// ranges straight from LDS.  Same arithmetic as k_project_verts + k_face_bins, one launch instead of two and no
+// global gathers for the bins.
+#define MVR_PB_BLOCK 1024
+#define MVR_PB_LDS_VERTS 12288   // 12288 * 12 B = 144 KiB
+__device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n, unsigned char *smem, int V, int H, int W, int G,
+                                                       int stride, int cull_backfaces, const float *__restrict__ R,
+                                                       const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
+                                                       unsigned short *__restrict__ bins) {
+  float *pl = (float *)smem;   // 3 * nv
+  const int b = n / V, v = n - b * V;
+  const int vo = m.vert_off[b], nv = m.vert_off[b + 1] - vo;
+  const int fo = m.face_off[b], nf = m.face_off[b + 1] - fo;
+  float Rm[9], Tv[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rm[k] = R[9 * (size_t)n + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) Tv[k] = T[3 * (size_t)n + k];
+  float4 *__restrict__ proj = proj_all + (size_t)V * vo + (size_t)v * nv;
+  for (int i = threadIdx.x; i < nv; i += MVR_PB_BLOCK) {
+    const float *p = m.verts + 3 * (size_t)(vo + i);
+    const f3 q = mvr::project_vertex<float>(Rm, Tv, s, {p[0], p[1], p[2]});
+    pl[3 * i] = q.x; pl[3 * i + 1] = q.y; pl[3 * i + 2] = q.z;
+    proj[i] = make_float4(q.x, q.y, q.z, 0.f);
+  }
+  __syncthreads();
+  const float px_lo = mvr::pix_to_ndc<float>(0, W), px_hi = mvr::pix_to_ndc<float>(W - 1, W);
+  const float py_lo = mvr::pix_to_ndc<float>(0, H), py_hi = mvr::pix_to_ndc<float>(H - 1, H);
+  for (int f = threadIdx.x; f < nf; f += MVR_PB_BLOCK) {
+    const int32_t *__restrict__ fc = m.faces + 3 * (size_t)(fo + f);
+    const int i0 = fc[0], i1 = fc[1], i2 = fc[2];
+    const f3 v0 = {pl[3 * i0], pl[3 * i0 + 1], pl[3 * i0 + 2]};
+    const f3 v1 = {pl[3 * i1], pl[3 * i1 + 1], pl[3 * i1 + 2]};
+    const f3 v2 = {pl[3 * i2], pl[3 * i2 + 1], pl[3 * i2 + 2]};
+    bins[(size_t)n * stride + f] = face_bin_range(v0, v1, v2, H, W, G, cull_backfaces, px_lo, px_hi, py_lo, py_hi);
+  }
+}
+
+__global__ void __launch_bounds__(MVR_PB_BLOCK) k_project_bins_view(MeshPtrs m, int V, int H, int W, int G, int stride,
+                                                                    int cull_backfaces, const float *__restrict__ R,
+                                                                    const float *__restrict__ T, float s,
+                                                                    float4 *__restrict__ proj_all, unsigned short *__restrict__ bins) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  project_bins_view_body(m, blockIdx.x, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins);
+}
+
+// Pre-pass in ONE launch: workgroups [0, B) build the per-mesh vertex attributes (position + normal), workgroups
+// [B, B + N) project one view each and bin its faces.  The two halves are independent, so they simply run
+// concurrently on different CUs (no second stream, no event round trips between queues).
+__global__ void __launch_bounds__(1024) k_mesh_prepass(MeshPtrs m, int V, int H, int W, int G, int stride, int cull_backfaces,
+                                                      const float *__restrict__ R, const float *__restrict__ T, float s,
+                                                      float4 *__restrict__ proj_all, unsigned short *__restrict__ bins,
+                                                      float4 *__restrict__ vattr) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if ((int)blockIdx.x < m.B) vattr_mesh_lds_body(m, blockIdx.x, smem, vattr, nullptr);
+  else project_bins_view_body(m, (int)blockIdx.x - m.B, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins);
 }
 
 struct RasterArgs {
@@ -1330,19 +1401,37 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   const int n_strips = (H + TH - 1) / TH;
   MeshPtrs mp = {meshes->verts, meshes->faces, meshes->vert_off, meshes->face_off, meshes->vert_colors, meshes->n_meshes};
 
-  rc = launch_vattr(meshes, ws, nullptr, st);
-  if (rc != MVR_OK) return rc;
-
   const float s = mvr::fov_scale(params->fov_deg);
-  int max_verts = meshes->max_verts > 0 ? meshes->max_verts : meshes->total_verts;
-  hipLaunchKernelGGL(k_project_verts, dim3((max_verts + MVR_BLOCK - 1) / MVR_BLOCK, N), dim3(MVR_BLOCK), 0, st, mp, V, R, T, s, ws.proj);
-  HIP_TRY(hipGetLastError());
-
-  const int G = bin_rows_for(H, TH);
+  const int max_verts = meshes->max_verts > 0 ? meshes->max_verts : meshes->total_verts;
   const int max_faces = meshes->max_faces > 0 ? meshes->max_faces : meshes->total_faces;
-  hipLaunchKernelGGL(k_face_bins, dim3((max_faces + MVR_BLOCK - 1) / MVR_BLOCK, N), dim3(MVR_BLOCK), 0, st, mp, V, H, W, G,
-                     ws.bin_stride, (params->flags & MVR_CULL_BACKFACES) ? 1 : 0, ws.proj, ws.bins);
-  HIP_TRY(hipGetLastError());
+  const int G = bin_rows_for(H, TH);
+  const int cullf = (params->flags & MVR_CULL_BACKFACES) ? 1 : 0;
+  if (max_verts <= MVR_NRM_LDS_VERTS && max_verts <= MVR_PB_LDS_VERTS) {
+    // one pre-pass launch: per-mesh vertex attributes + per-view projection/binning side by side
+    const size_t lds_pp = (size_t)3 * max_verts * sizeof(unsigned long long);   // >= the 12 B/vertex the projection half needs
+    if (lds_pp > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp));
+    hipLaunchKernelGGL(k_mesh_prepass, dim3(meshes->n_meshes + N), dim3(1024), lds_pp, st, mp, V, H, W, G, ws.bin_stride, cullf, R, T,
+                       s, ws.proj, ws.bins, ws.vattr);
+    HIP_TRY(hipGetLastError());
+  } else {
+    rc = launch_vattr(meshes, ws, nullptr, st);
+    if (rc != MVR_OK) return rc;
+    if (max_verts <= MVR_PB_LDS_VERTS) {
+      const size_t lds_pb = (size_t)3 * max_verts * sizeof(float);
+      if (lds_pb > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)k_project_bins_view, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pb));
+      hipLaunchKernelGGL(k_project_bins_view, dim3(N), dim3(MVR_PB_BLOCK), lds_pb, st, mp, V, H, W, G, ws.bin_stride, cullf, R, T, s,
+                         ws.proj, ws.bins);
+      HIP_TRY(hipGetLastError());
+    } else {
+      hipLaunchKernelGGL(k_project_verts, dim3((max_verts + MVR_BLOCK - 1) / MVR_BLOCK, N), dim3(MVR_BLOCK), 0, st, mp, V, R, T, s, ws.proj);
+      HIP_TRY(hipGetLastError());
+      hipLaunchKernelGGL(k_face_bins, dim3((max_faces + MVR_BLOCK - 1) / MVR_BLOCK, N), dim3(MVR_BLOCK), 0, st, mp, V, H, W, G,
+                         ws.bin_stride, cullf, ws.proj, ws.bins);
+      HIP_TRY(hipGetLastError());
+    }
+  }
 
   RasterArgs a;
   a.bins = ws.bins; a.bin_rows = G; a.bin_stride = ws.bin_stride;

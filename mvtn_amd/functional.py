@@ -32,7 +32,7 @@ def _ptr(t):
 
 class _LookAt(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, azim, elev, dist, max_trials, seed):
+    def forward(ctx, azim, elev, dist, max_trials, seed, host_status=None):
         lib = _lib.load()
         azim, elev, dist = _f32c(azim), _f32c(elev), _f32c(dist)
         _require_cuda(azim, elev, dist)
@@ -43,9 +43,11 @@ class _LookAt(torch.autograd.Function):
         status = torch.empty(n + 2, dtype=torch.int32, device=dev)  # [0] re-draws, [1] #invalid, [2:] per-view valid
         if max_trials >= 0:
             used = torch.empty(2, n, dtype=torch.float32, device=dev)
+            # host_status: 2 pinned int32 words the kernel writes directly (zero-copy) — no D2H copy on the stream
+            sp = status.data_ptr() if host_status is None else host_status.data_ptr()
             _lib.check(lib.mvr_look_at_checked(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), n, int(max_trials),
                                                int(seed) & 0xFFFFFFFFFFFFFFFF, R.data_ptr(), T.data_ptr(), used[0].data_ptr(),
-                                               used[1].data_ptr(), status[2:].data_ptr(), status.data_ptr(), _stream()),
+                                               used[1].data_ptr(), status[2:].data_ptr(), sp, _stream()),
                        "mvr_look_at_checked")
             ctx.save_for_backward(used[0], used[1], dist)
         else:
@@ -65,17 +67,18 @@ class _LookAt(torch.autograd.Function):
         ga, ge, gd = torch.empty_like(azim), torch.empty_like(elev), torch.empty_like(dist)
         _lib.check(lib.mvr_look_at_backward(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), n, _ptr(gR), _ptr(gT),
                                             ga.data_ptr(), ge.data_ptr(), gd.data_ptr(), _stream()), "mvr_look_at_backward")
-        return ga, ge, gd, None, None
+        return ga, ge, gd, None, None, None
 
 
-def look_at_view_transform(dist, elev, azim, return_status=False, max_trials=-1, seed=0):
+def look_at_view_transform(dist, elev, azim, return_status=False, max_trials=-1, seed=0, host_status=None):
     """R (N,3,3), T (N,3) for flat per-view (N,) distance / elevation / azimuth in degrees —
     pytorch3d look_at_view_transform as called at models/renderer.py:79-80 — differentiable.
     status (int32, N+2): [0] = remedy re-draws performed, [1] = number of views failing
     check_valid_rotation_matrix (util.py:403-420), [2:] = per-view validity; all computed on the
     device without a host sync.  max_trials >= 0 enables the device-side remedy loop of
-    ops.py:156-165 (see mvr_look_at_checked in include/mvr.h)."""
-    R, T, status = _LookAt.apply(azim.reshape(-1), elev.reshape(-1), dist.reshape(-1), max_trials, seed)
+    ops.py:156-165 (see mvr_look_at_checked in include/mvr.h); with `host_status` (2 pinned int32 words)
+    the kernel writes status[0:2] straight into host memory instead of the returned device tensor."""
+    R, T, status = _LookAt.apply(azim.reshape(-1), elev.reshape(-1), dist.reshape(-1), max_trials, seed, host_status)
     return (R, T, status) if return_status else (R, T)
 
 

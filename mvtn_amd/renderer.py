@@ -50,7 +50,9 @@ class MVRenderer(nn.Module):
             raise ValueError("rotation_check must be 'device', 'sync' or 'off'")
         self.rotation_check = rotation_check
         self._calls = 0
-        self._pending = []  # (event, pinned status copy) of earlier forwards, "device" mode
+        self._pending = []  # (event, pinned status words written by the kernel) of earlier forwards, "device" mode
+        self._status_pool = []  # recycled pinned status buffers
+        self._light_cache = {}  # (device, direction tuple) -> (1,3) tensor
         self.strip_rows = strip_rows
         # faces_per_pixel > 1 does not change a HardPhongShader image (hard_rgb_blend reads only
         # the nearest face), so any value >= 1 renders identically; points_per_pixel > 1 would.
@@ -83,10 +85,10 @@ class MVRenderer(nn.Module):
             self.check_status(block=False)
             self._calls += 1
             seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+            host = self._status_pool.pop() if self._status_pool else torch.zeros(2, dtype=torch.int32, pin_memory=True)
             R, T, status = F.look_at_view_transform(flatten_views(dist), flatten_views(elev), flatten_views(azim),
-                                                    return_status=True, max_trials=EXAHSTION_LIMIT, seed=seed)
-            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
-            host.copy_(status[:2], non_blocking=True)
+                                                    return_status=True, max_trials=EXAHSTION_LIMIT, seed=seed,
+                                                    host_status=host)
             ev = torch.cuda.Event()
             ev.record()
             self._pending.append((ev, host))
@@ -106,6 +108,7 @@ class MVRenderer(nn.Module):
             if int(host[1]) != 0:
                 self._pending = []
                 sys.exit("Remedy did not work")
+            self._status_pool.append(host)
         self._pending = keep
 
     def _remedy(self, azim, elev, dist):
@@ -136,7 +139,12 @@ class MVRenderer(nn.Module):
         if torch.is_tensor(lights):
             light = lights
         else:
-            light = torch.tensor(lights, dtype=torch.float32).reshape(-1, 3).to(device, non_blocking=True)
+            key = (str(device), tuple(float(c) for row in lights for c in row))
+            light = self._light_cache.get(key)
+            if light is None:
+                light = torch.tensor(lights, dtype=torch.float32).reshape(-1, 3).to(device)
+                if self.light_direction_type == "fixed":
+                    self._light_cache[key] = light
         params = F.mesh_params(self.nb_views, self.image_size, light.shape[0], obj, [float(c) for c in background_color],
                                cull_backfaces=bool(self.cull_backfaces), perspective_correct=bool(self.perspective_correct),
                                strip_rows=self.strip_rows)
