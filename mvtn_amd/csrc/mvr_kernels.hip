@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/mvr.h"
@@ -34,9 +35,9 @@ typedef V3<float> f3;
 
 #define MVR_BLOCK 256
 #define MVR_WAVES (MVR_BLOCK / 64)
-#define MVR_SCAN_PER_LANE 4     // faces per lane per scan round (one 8-byte vector of 2-byte row-bin ranges)
-#define MVR_LIST_CAP 1536       // LDS face list (4 B entries): flushed before a worst-case scan round (1024) could overflow it
+#define MVR_LIST_CAP 1536       // LDS face list (4 B entries); a strip touched by more faces is processed in windows of this size
 #define MVR_BATCH 256           // faces set up / rasterised per batch (one per lane in the setup phase)
+#define MVR_V3_ROUNDS 4          // scan: 8 faces per lane per round -> 256 * 8 * 4 = 8192 faces per pass
 #define MVR_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define MVR_NACC 18
 
@@ -598,44 +599,55 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
   unsigned long long t_scan = 0, t_small = 0, t_large = 0, n_small_tot = 0, n_large_tot = 0;
   unsigned long long tc0 = clock64();
 #endif
-  uint2 q_next = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-  if (tid * MVR_SCAN_PER_LANE < nf) q_next = *reinterpret_cast<const uint2 *>(bins + tid * MVR_SCAN_PER_LANE);
-  for (int base = 0; base < nf; base += MVR_BLOCK * MVR_SCAN_PER_LANE) {
-    // ---- scan: 4 faces (one 8-byte vector of row-bin ranges) per lane; compact hits into the LDS list ----
-    const int f0 = base + tid * MVR_SCAN_PER_LANE;
-    const uint2 q = q_next;
-    {  // prefetch the next round's vector: its latency hides behind this round's ballots / raster batches
-      const int fn = f0 + MVR_BLOCK * MVR_SCAN_PER_LANE;
-      if (fn < nf) q_next = *reinterpret_cast<const uint2 *>(bins + fn);
-    }
-    unsigned hit = 0;
-    if (f0 < nf) {
-      const unsigned w[2] = {q.x, q.y};
+  const int faces_per_pass = MVR_BLOCK * 8 * MVR_V3_ROUNDS;
+  for (int pbase = 0; pbase < nf; pbase += faces_per_pass) {
+    // ---- scan: the row-bin vectors of up to 8192 faces are requested up front (4 x 16 B per lane); hit masks
+    //      stay in registers; one wave prefix sum + ONE LDS atomic per wave orders the hits ---------------------
+    uint4 q[MVR_V3_ROUNDS];
 #pragma unroll
-      for (int k = 0; k < MVR_SCAN_PER_LANE; ++k) {
-        unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
-        unsigned e0 = e & 0xffu, e1 = e >> 8;
-        bool h = (e != MVR_BIN_NONE) && e0 <= g_hi && e1 >= g_lo && (f0 + k) < nf;
-        hit |= (h ? 1u : 0u) << k;
+    for (int r = 0; r < MVR_V3_ROUNDS; ++r) {
+      const int f0 = pbase + (r * MVR_BLOCK + tid) * 8;
+      q[r] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      if (f0 < nf) q[r] = *reinterpret_cast<const uint4 *>(bins + f0);
+    }
+    unsigned mask = 0;   // bit (8 r + k): face pbase + (r * BLOCK + tid) * 8 + k touches this strip
+#pragma unroll
+    for (int r = 0; r < MVR_V3_ROUNDS; ++r) {
+      const int f0 = pbase + (r * MVR_BLOCK + tid) * 8;
+      const unsigned w[4] = {q[r].x, q[r].y, q[r].z, q[r].w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+        const bool h = (e != MVR_BIN_NONE) && (e & 0xffu) <= g_hi && (e >> 8) >= g_lo && (f0 + k) < nf;
+        mask |= (h ? 1u : 0u) << (8 * r + k);
       }
     }
+    const int my_hits = __popc(mask);
+    int hincl = my_hits;
 #pragma unroll
-    for (int k = 0; k < MVR_SCAN_PER_LANE; ++k) {
-      const bool h = (hit >> k) & 1u;
-      unsigned long long mh = __ballot(h);
-      if (mh) {  // wave-uniform
-        int bs = 0;
-        if (lane == 0) bs = atomicAdd(&cnt[0], __popcll(mh));
-        bs = __shfl(bs, 0);
-        if (h) list[bs + __popcll(mh & ((1ull << lane) - 1ull))] = f0 + k;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(hincl, off);
+      if (lane >= off) hincl += t;
+    }
+    int wave_base = 0;
+    if (lane == 63 && hincl) wave_base = atomicAdd(&cnt[0], hincl);
+    wave_base = __shfl(wave_base, 63);
+    const int my_pos = wave_base + hincl - my_hits;   // rank of this lane's first hit in the pass
+    __syncthreads();
+    const int total_hits = cnt[0];
+    for (int win = 0; win < total_hits; win += MVR_LIST_CAP) {
+    {  // materialise hits [win, win + CAP) of the pass in the LDS list
+      int pos = my_pos - win;
+      unsigned m = mask;
+      while (m) {
+        const int bit = __ffs(m) - 1;
+        m &= m - 1;
+        if (pos >= 0 && pos < MVR_LIST_CAP) list[pos] = pbase + ((bit >> 3) * MVR_BLOCK + tid) * 8 + (bit & 7);
+        ++pos;
       }
     }
-    // LDS-only barrier: a plain __syncthreads() would also wait for the prefetched global load (vmcnt(0))
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    const int n_list = cnt[0];
-    const bool last = base + MVR_BLOCK * MVR_SCAN_PER_LANE >= nf;
-    if (!last && n_list + MVR_BLOCK * MVR_SCAN_PER_LANE <= MVR_LIST_CAP) continue;  // room for a worst-case scan round
+    __syncthreads();
+    const int n_list = min(MVR_LIST_CAP, total_hits - win);
 #ifdef MVR_DIAG
     unsigned long long tc1 = clock64();
     t_scan += tc1 - tc0; n_small_tot += n_list;
@@ -737,7 +749,8 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
 #ifdef MVR_DIAG
     tc0 = clock64();
 #endif
-    if (!last) {
+    }   // window
+    if (pbase + faces_per_pass < nf) {
       if (tid == 0) cnt[0] = 0;
       __syncthreads();
     }
