@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--rotation-check", default="device", choices=["device", "sync", "off"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--cpu-views", type=int, default=4, help="views in the cpu_baseline sample")
+    ap.add_argument("--cpu-views", type=int, default=16, help="views in the cpu_baseline sample (~0.7 s each for meshes)")
     return ap.parse_args()
 
 

@@ -369,3 +369,80 @@ def test_full_size_properties():
     img, _ = r1(sph, None, _t([[30.0]]), _t([[20.0]]), _t([[2.2]]))
     frac = float((img[0, 0].sum(0) > 0).float().mean())
     assert abs(frac - 0.6136) < 0.004, frac
+
+
+def _render_pair(oracle, vl, fl, az, el, di, size, strip=0, persp=True):
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    B, V = az.shape
+    obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
+    want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, perspective_correct=persp, mode=1)
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    params = F.mesh_params(V, size, 1, obj, bg, perspective_correct=persp, strip_rows=strip)
+    img, p2f = F.render_meshes_fragments(packed, R, T, _t([[0, 1, 0]]), params)
+    return img.cpu().numpy(), p2f.cpu().numpy(), want
+
+
+def test_edge_case_flat_band_many_faces_per_strip(oracle):
+    """20 480 faces squeezed into a few image rows: > 8192 faces (several scan passes) and far more than
+    MVR_LIST_CAP faces touching one strip (list windows), thousands of coincident-depth candidates per pixel."""
+    v, f = syn.synthetic_mesh("L", 3)
+    v = v.copy()
+    v[:, 1] *= 0.03
+    az, el, di = np.array([[20.0, 200.0]], np.float32), np.array([[0.0, 3.0]], np.float32), np.full((1, 2), 2.2, np.float32)
+    img, p2f, want = _render_pair(oracle, [v], [f], az, el, di, 224)
+    assert int((p2f != want["pix_to_face"]).sum()) == 0
+    assert (p2f >= 0).sum() > 1000
+    well = _well_conditioned_pixels([v], [f], want["pix_to_face"], 2)
+    assert np.abs(img - want["images"]).reshape(2, 3, 224, 224).max(1)[well].max() <= TOL_PIXEL
+
+
+def test_edge_case_huge_and_tiny_faces(oracle):
+    """Two triangles covering the whole frame (every strip, every lane of the balanced loop shares one face), a
+    sub-pixel sliver, a degenerate (zero-area) face and a face behind the camera."""
+    big = [[-4, -4, 0.1], [4, -4, 0.1], [0, 4, 0.1], [-4, 4, -0.2], [4, 4, -0.2], [0, -4, -0.2]]
+    sliver = [[0.0, 0.0, 0.5], [0.004, 0.0, 0.5], [0.0, 0.004, 0.5]]
+    degenerate = [[0.1, 0.1, 0.6], [0.2, 0.2, 0.6], [0.3, 0.3, 0.6]]
+    behind = [[-1, -1, 5.0], [1, -1, 5.0], [0, 1, 5.0]]
+    v = np.asarray(big + sliver + degenerate + behind, np.float32)
+    f = np.arange(len(v)).reshape(-1, 3).astype(np.int64)
+    az, el, di = np.array([[0.0, 10.0, 180.0]], np.float32), np.array([[0.0, 5.0, 0.0]], np.float32), np.full((1, 3), 2.2, np.float32)
+    for size, strip in ((64, 0), (224, 0), (50, 3)):
+        img, p2f, want = _render_pair(oracle, [v], [f], az, el, di, size, strip=strip)
+        assert int((p2f != want["pix_to_face"]).sum()) == 0, (size, strip)
+        assert np.abs(img - want["images"]).max() <= TOL_PIXEL
+        assert (p2f[0] >= 0).mean() > 0.9
+
+
+def test_edge_case_nothing_visible_and_large_image(oracle):
+    """Object behind / beside the camera -> pure background; a 300^2 image (more than 254 rows: row-bins of 2 strips)."""
+    v, f = syn.synthetic_mesh("S", 0)
+    far = v + np.array([0.0, 0.0, 50.0], np.float32)
+    az, el, di = np.array([[0.0]], np.float32), np.array([[0.0]], np.float32), np.array([[2.2]], np.float32)
+    img, p2f, want = _render_pair(oracle, [far], [f], az, el, di, 96)
+    assert (p2f == -1).all() and np.array_equal(p2f, want["pix_to_face"])
+    assert np.allclose(img[0, 0, 0], 0.1) and np.allclose(img[0, 0, 2], 0.3)
+    img, p2f, want = _render_pair(oracle, [v], [f], az, el, di, 300, persp=False)
+    assert int((p2f != want["pix_to_face"]).sum()) == 0 and np.abs(img - want["images"]).max() <= TOL_PIXEL
+    img, p2f, want = _render_pair(oracle, [v], [f], az, el, di, 2200 // 4, strip=2)   # 550 rows / 2 = 275 strips > 254 bins
+    assert int((p2f != want["pix_to_face"]).sum()) == 0
+
+
+def test_edge_case_points_ragged_counts(oracle):
+    """P not a multiple of the 4-point scan vector, points behind the camera, off-screen, and stacked at one pixel."""
+    from mvtn_amd import functional as F
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-0.8, 0.8, (2, 1027, 3)).astype(np.float32)
+    pts[0, :5] = [0.1, 0.1, 0.0]            # five identical points: smallest index wins
+    pts[1, :50, 2] = 7.0                    # far off along +z (behind the orthographic camera after T)
+    pts[1, 50:60, 0] = 9.0                  # off-screen
+    az, el = np.array([[0.0, 77.0]] * 2, np.float32), np.array([[0.0, -20.0]] * 2, np.float32)
+    di = np.array([[1.0, 1.4]] * 2, np.float32)
+    want = oracle.render_points(pts, az, el, di, 100, radius=0.03, obj_color=(1, 1, 1), bg_color=(0, 0, 0))
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    for strip in (0, 1, 9):
+        params = F.points_params(2, 1027, 2, 100, 0.03, (1, 1, 1), (0, 0, 0), strip_rows=strip)
+        img, idx = F.render_points_fragments(_t(pts), None, R, T, _t(di.reshape(-1)), params)
+        assert int((idx.cpu().numpy() != want["idx"]).sum()) == 0, strip
+        assert np.abs(img.cpu().numpy() - want["images"]).max() <= 1e-6

@@ -190,3 +190,25 @@ def test_mvrenderer_mode_switches():
         MVRenderer(4, 32, points_per_pixel=5)
     with pytest.raises(ValueError):
         MVRenderer(4, 32, rotation_check="maybe")
+
+
+def test_view_selectors_match_reference(golden):
+    """models/mvtn.py:13-111 restated in mvtn_amd/views.py: buffers, (B,V) stride-(0,1) outputs, dispatch."""
+    from mvtn_amd.views import RandomViewSelector, view_selector
+    for key, g in golden["selectors"].items():
+        cfg, V = key.split("_")
+        sel = view_selector(cfg, int(V), canonical_elevation=30.0, canonical_distance=2.2).eval()
+        az, el, di = sel(None, c_batch_size=3)
+        assert list(az.shape) == g["shape"] and list(az.stride()) == g["stride"]
+        assert np.allclose(az[0].numpy(), g["azim"], atol=1e-4) and np.allclose(el[0].numpy(), g["elev"], atol=1e-4)
+        assert az[2].tolist() == az[0].tolist() and di[1].tolist() == g["dist"]
+    torch.manual_seed(0)
+    az, el, di = RandomViewSelector(8, transform_distance=True)(None, c_batch_size=5)
+    assert az.shape == (5, 8) and float(az.min()) >= -180 and float(az.max()) < 180
+    assert float(el.min()) >= -90 and float(el.max()) < 90 and float(di.min()) > 2.2 * 0.5 and float(di.max()) < 2.2 * 1.51
+    noisy = view_selector("spherical", 12, input_view_noise=0.1).train()
+    a1, _, _ = noisy(None, 2)
+    a2, _, _ = noisy(None, 2)
+    assert not torch.equal(a1, a2) and a1.shape == (2, 12)
+    with pytest.raises(NotImplementedError):
+        view_selector("learned_spherical", 12)
