@@ -570,6 +570,7 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
   int *cum = (int *)(rng + MVR_BATCH);                                         // MVR_BATCH + 1 exclusive prefix sums
   int *list = cum + (MVR_BATCH + 1);                                           // MVR_LIST_CAP face indices
   int *cnt = list + MVR_LIST_CAP;                                              // [0] list entries, [1..4] wave totals
+  __shared__ int start[MVR_BLOCK];                                             // first face of every lane's run
 
   int n, strip;
   decode_block(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
@@ -590,7 +591,6 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
   // pixel centre of NDC index i: -1 + (2 i + 1)/S, the division done as div_by with RN(1/S): bit-identical
   const float fW = (float)W, fH = (float)H, invW = 1.0f / fW, invH = 1.0f / fH;
 
-  for (int i = tid; i < rows * W; i += MVR_BLOCK) keys[i] = MVR_KEY_EMPTY;
   if (tid == 0) cnt[0] = 0;
   __syncthreads();
 
@@ -610,6 +610,7 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
       q[r] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
       if (f0 < nf) q[r] = *reinterpret_cast<const uint4 *>(bins + f0);
     }
+    if (pbase == 0) for (int i = tid; i < rows * W; i += MVR_BLOCK) keys[i] = MVR_KEY_EMPTY;   // under the loads' latency
     unsigned mask = 0;   // bit (8 r + k): face pbase + (r * BLOCK + tid) * 8 + k touches this strip
 #pragma unroll
     for (int r = 0; r < MVR_V3_ROUNDS; ++r) {
@@ -696,16 +697,20 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
 #endif
       // ---- raster: balanced split of the batch's `total` (face, pixel) candidates over 256 lanes -------
       const int quota = (total + MVR_BLOCK - 1) / MVR_BLOCK;
+      // face e owns the lanes whose run starts inside [cum[e], cum[e] + my_cnt): lanes ceil(cum[e]/quota) ... ;
+      // it writes its own index into start[] for them (no dependent LDS chain, unlike a binary search per lane)
+      if (my_cnt > 0) {
+        const int c0 = wave_off + incl - my_cnt;
+        int l0 = (c0 + quota - 1) / quota, l1 = (c0 + my_cnt - 1) / quota;
+        if (l1 > MVR_BLOCK - 1) l1 = MVR_BLOCK - 1;
+        for (int l = l0; l <= l1; ++l) start[l] = tid;
+      }
+      __syncthreads();
       const int p0 = tid * quota;
       int rem = min(quota, total - p0);
       if (rem > 0) {
         // e = last entry with cum[e] <= p0  (upper_bound - 1); entries with zero candidates are skipped by it
-        int lo = 0, hi = MVR_BATCH;  // invariant: cum[lo] <= p0 < cum[hi]
-        while (hi - lo > 1) {
-          int mid = (lo + hi) >> 1;
-          if (cum[mid] <= p0) lo = mid; else hi = mid;
-        }
-        int e = lo;
+        int e = start[tid];   // the face whose candidates contain item p0 (written by that face's setup lane)
         mvr::FaceSetup<float> fs;
         int f, x0, x1, y0, y1, ix, jy, left;
         {
