@@ -483,7 +483,9 @@ __device__ __forceinline__ void decode_block(int bid, int n_strips, int views_pe
 // backward kernel and the host tests); observed difference ~1e-6.
 struct ShadeConst {
   f3 lh;            // normalised light direction (per view)
-  f3 cc;            // camera centre
+  float Rm[9];      // camera rotation (view -> world for directions: d_world = d_view R^T)
+  float inv_s;      // 1 / projection scale
+  f3 cc;            // camera centre (only for perspective_correct = false)
   f3 objc;
   float ambient, diffuse, specular, shininess;
   const float4 *vat;
@@ -491,8 +493,8 @@ struct ShadeConst {
 };
 
 __device__ __forceinline__ f3 shade_fast(const f3 &P0, const f3 &P1, const f3 &P2, float px, float py, bool persp,
-                                         const f3 &X0, const f3 &X1, const f3 &X2, const f3 &N0, const f3 &N1, const f3 &N2,
-                                         const f3 &c0, const f3 &c1, const f3 &c2, const ShadeConst &sh) {
+                                         const f3 &N0, const f3 &N1, const f3 &N2,
+                                         const f3 &c0, const f3 &c1, const f3 &c2, const ShadeConst &sh, int i0, int i1, int i2) {
 #pragma clang fp contract(fast)
   const float e0 = (px - P1.x) * (P2.y - P1.y) - (py - P1.y) * (P2.x - P1.x);
   const float e1 = (px - P2.x) * (P0.y - P2.y) - (py - P2.y) * (P0.x - P2.x);
@@ -505,14 +507,27 @@ __device__ __forceinline__ f3 shade_fast(const f3 &P0, const f3 &P1, const f3 &P
     const float rd = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, mvr::kEps));
     w0 = t0 * rd; w1 = t1 * rd; w2 = t2 * rd;
   }
-  const f3 p = {w0 * X0.x + w1 * X1.x + w2 * X2.x, w0 * X0.y + w1 * X1.y + w2 * X2.y, w0 * X0.z + w1 * X1.z + w2 * X2.z};
+  // The interpolated world position p = sum w_i X_i only feeds the view direction C - p.  With perspective-correct
+  // barycentrics p is exactly where the pixel ray meets the triangle, so in VIEW space (camera at the origin) it is
+  // (px z / s, py z / s, z) with z = sum w_i z_i, and (C - p) = -(x_v, y_v, z_v) R^T: no vertex-position gathers.
+  // With perspective_correct = false PyTorch3D's p is the screen-space interpolation (not on the ray): gather X.
+  f3 view;
+  if (persp) {
+    const float zv = w0 * P0.z + w1 * P1.z + w2 * P2.z;
+    const float xv = px * zv * sh.inv_s, yv = py * zv * sh.inv_s;
+    view = {-(xv * sh.Rm[0] + yv * sh.Rm[1] + zv * sh.Rm[2]), -(xv * sh.Rm[3] + yv * sh.Rm[4] + zv * sh.Rm[5]),
+            -(xv * sh.Rm[6] + yv * sh.Rm[7] + zv * sh.Rm[8])};
+  } else {
+    const f3 X0 = ld3(sh.vat + 2 * i0), X1 = ld3(sh.vat + 2 * i1), X2 = ld3(sh.vat + 2 * i2);
+    view = {sh.cc.x - (w0 * X0.x + w1 * X1.x + w2 * X2.x), sh.cc.y - (w0 * X0.y + w1 * X1.y + w2 * X2.y),
+            sh.cc.z - (w0 * X0.z + w1 * X1.z + w2 * X2.z)};
+  }
   const f3 nn = {w0 * N0.x + w1 * N1.x + w2 * N2.x, w0 * N0.y + w1 * N1.y + w2 * N2.y, w0 * N0.z + w1 * N1.z + w2 * N2.z};
   const f3 tex = {w0 * c0.x + w1 * c1.x + w2 * c2.x, w0 * c0.y + w1 * c1.y + w2 * c2.y, w0 * c0.z + w1 * c1.z + w2 * c2.z};
   const float eps2 = mvr::kNormalizeEps * mvr::kNormalizeEps;
   const float rn = __builtin_amdgcn_rsqf(fmaxf(nn.x * nn.x + nn.y * nn.y + nn.z * nn.z, eps2));  // v / max(|v|, eps)
   const f3 nh = {nn.x * rn, nn.y * rn, nn.z * rn};
   const float cosang = nh.x * sh.lh.x + nh.y * sh.lh.y + nh.z * sh.lh.z;
-  const f3 view = {sh.cc.x - p.x, sh.cc.y - p.y, sh.cc.z - p.z};
   const float rv = __builtin_amdgcn_rsqf(fmaxf(view.x * view.x + view.y * view.y + view.z * view.z, eps2));
   const float two_c = 2.0f * cosang;
   const f3 refl = {two_c * nh.x - sh.lh.x, two_c * nh.y - sh.lh.y, two_c * nh.z - sh.lh.z};
@@ -781,6 +796,9 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
     for (int k = 0; k < 9; ++k) Rm[k] = a.R[9 * (size_t)n + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) Tv[k] = a.T[3 * (size_t)n + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sh.Rm[k] = Rm[k];
+    sh.inv_s = 1.0f / a.s;
     sh.cc = mvr::camera_center<float>(Rm, Tv);
     const float *lp = a.light + 3 * (size_t)(a.n_light == 1 ? 0 : n);
     sh.lh = mvr::normalize<float>({lp[0], lp[1], lp[2]}, mvr::kNormalizeEps);
@@ -828,7 +846,6 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
     }
     while (e < n_cov) {
       const f3 P0 = ld3(proj + i0), P1 = ld3(proj + i1), P2 = ld3(proj + i2);
-      const f3 X0 = ld3(sh.vat + 2 * i0), X1 = ld3(sh.vat + 2 * i1), X2 = ld3(sh.vat + 2 * i2);
       const f3 N0 = ld3(sh.vat + 2 * i0 + 1), N1 = ld3(sh.vat + 2 * i1 + 1), N2 = ld3(sh.vat + 2 * i2 + 1);
       f3 c0 = sh.objc, c1 = sh.objc, c2 = sh.objc;
       if (sh.vcol) {
@@ -836,7 +853,7 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
         c1 = {sh.vcol[3 * i1], sh.vcol[3 * i1 + 1], sh.vcol[3 * i1 + 2]};
         c2 = {sh.vcol[3 * i2], sh.vcol[3 * i2 + 1], sh.vcol[3 * i2 + 2]};
       }
-      const int cur_pix = pix, cur_face = face;
+      const int cur_pix = pix, cur_face = face, ci0 = i0, ci1 = i1, ci2 = i2;
       e += MVR_BLOCK;
       if (e < n_cov) {  // prefetch the next pixel's indices
         pix = plist[e];
@@ -846,7 +863,7 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
       const int row = cur_pix / W, col = cur_pix - row * W;
       const float px = -1.0f + mvr::div_by(2.0f * (float)(W - 1 - col) + 1.0f, fW, invW);
       const float py = -1.0f + mvr::div_by(2.0f * (float)(jy_hi - row) + 1.0f, fH, invH);
-      const f3 rgb = shade_fast(P0, P1, P2, px, py, persp, X0, X1, X2, N0, N1, N2, c0, c1, c2, sh);
+      const f3 rgb = shade_fast(P0, P1, P2, px, py, persp, N0, N1, N2, c0, c1, c2, sh, ci0, ci1, ci2);
       img[cur_pix] = rgb.x; img[HW + cur_pix] = rgb.y; img[2 * HW + cur_pix] = rgb.z;
       if (p2f) p2f[cur_pix] = cur_face;
     }

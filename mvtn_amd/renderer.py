@@ -28,6 +28,7 @@ from .structures import Cameras, PackedMeshes
 
 ORTHOGONAL_THRESHOLD = 1e-6
 EXAHSTION_LIMIT = 20  # models/renderer.py:30 (the reference's spelling)
+_STATUS_PENDING = -1   # sentinel in the pinned status words until the look-at kernel has written them
 
 
 class MVRenderer(nn.Module):
@@ -50,7 +51,7 @@ class MVRenderer(nn.Module):
             raise ValueError("rotation_check must be 'device', 'sync' or 'off'")
         self.rotation_check = rotation_check
         self._calls = 0
-        self._pending = []  # (event, pinned status words written by the kernel) of earlier forwards, "device" mode
+        self._pending = []  # pinned status words (written by the kernel) of earlier forwards, "device" mode
         self._status_pool = []  # recycled pinned status buffers
         self._light_cache = {}  # (device, direction tuple) -> (1,3) tensor
         self.strip_rows = strip_rows
@@ -85,13 +86,14 @@ class MVRenderer(nn.Module):
             self.check_status(block=False)
             self._calls += 1
             seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
-            host = self._status_pool.pop() if self._status_pool else torch.zeros(2, dtype=torch.int32, pin_memory=True)
+            # 2 pinned int32 words the kernel writes directly (zero-copy).  They are pre-set to a sentinel, so
+            # "has this forward's status landed?" is a plain host read: no event, no copy, nothing on the stream.
+            host = self._status_pool.pop() if self._status_pool else torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.fill_(_STATUS_PENDING)
             R, T, status = F.look_at_view_transform(flatten_views(dist), flatten_views(elev), flatten_views(azim),
                                                     return_status=True, max_trials=EXAHSTION_LIMIT, seed=seed,
                                                     host_status=host)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._pending.append((ev, host))
+            self._pending.append(host)
             return R, T, status
         return F.look_at_view_transform(flatten_views(dist), flatten_views(elev), flatten_views(azim), return_status=True)
 
@@ -99,12 +101,12 @@ class MVRenderer(nn.Module):
         """Raise the reference's sys.exit("Remedy did not work") if an earlier forward exhausted the
         device-side remedy.  block=False only looks at status words that have already landed."""
         keep = []
-        for ev, host in self._pending:
-            if block:
-                ev.synchronize()
-            elif not ev.query():
-                keep.append((ev, host))
-                continue
+        for host in self._pending:
+            if int(host[1]) == _STATUS_PENDING:
+                if not block:
+                    keep.append(host)
+                    continue
+                torch.cuda.synchronize()
             if int(host[1]) != 0:
                 self._pending = []
                 sys.exit("Remedy did not work")
