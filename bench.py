@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--rotation-check", default="device", choices=["device", "sync", "off"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (self-test of the N>1 code path)")
     ap.add_argument("--cpu-views", type=int, default=16, help="views in the cpu_baseline sample (~0.7 s each for meshes)")
     return ap.parse_args()
 
@@ -91,6 +92,11 @@ def cpu_baseline(args, V):
 
 def main():
     args = parse()
+    # Only the JSON line may reach stdout: libraries (RCCL prints a version banner on fd 1) are diverted to stderr
+    # until the result is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,10 +104,11 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist_on = world > 1
+    dist_on = world > 1 or args.force_dist
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, synthetic as syn
@@ -264,7 +271,10 @@ def main():
         }
         if gather:
             line["allgather"] = gather
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if dist_on:
         dist.destroy_process_group()
 
