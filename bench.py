@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--rotation-check", default="device", choices=["device", "sync", "off"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--host-meshes", action="store_true", help="hand CPU meshes to every step (the reference's interface): packing + H2D inside the timed region; documentation only, never the headline")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (self-test of the N>1 code path)")
     ap.add_argument("--cpu-views", type=int, default=16, help="views in the cpu_baseline sample (~0.7 s each for meshes)")
     return ap.parse_args()
@@ -144,6 +145,8 @@ def main():
             nv_list.append(len(v))
             nf_list.append(len(f))
         packed = PackedMeshes.from_meshes(Meshes(vl, fl), dev)  # inputs resident in HBM before the timed region
+        if args.host_meshes:
+            packed = [Meshes([v], [f]) for v, f in zip(vl, fl)]  # list of single-mesh objects on the CPU, as collate_fn yields
         light = "relative" if args.workload == "mesh_fwdbwd" else "fixed"
         renderer = MVRenderer(V, H, pc_rendering=False, object_color="white", background_color="white",
                               light_direction=light, rotation_check=args.rotation_check, strip_rows=args.strip_rows).eval()
@@ -247,8 +250,8 @@ def main():
             want = orc.render_points(points[:nb].cpu().numpy(), a_, e_, d_, H, radius=0.006, obj_color=(0.99999,) * 3,
                                      bg_color=(0.99999,) * 3, return_fragments=False)
         else:
-            vl = [packed.verts[int(packed.vert_off[i]):int(packed.vert_off[i + 1])].cpu().numpy() for i in range(nb)]
-            fl = [packed.faces[int(packed.face_off[i]):int(packed.face_off[i + 1])].cpu().numpy() for i in range(nb)]
+            vl = [vl[i].numpy() for i in range(nb)]
+            fl = [fl[i].numpy() for i in range(nb)]
             ld = orc.camera_position(a_, e_, d_) if args.workload == "mesh_fwdbwd" else ((0.0, 1.0, 0.0),)
             want = orc.render_meshes(vl, fl, a_, e_, d_, H, light_dir=ld, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3,
                                      return_fragments=False)
@@ -264,6 +267,7 @@ def main():
                                     "mesh_fwdbwd": "C3: B=16 tier-%s meshes x 12 jittered views, %dx%d, fwd+bwd (grad wrt azim/elev/dist, relative light)" % (args.tier, H, W),
                                     "points_fwd": "C4: B=20 clouds x 2048 pts x 20 views, %dx%d, point render fwd" % (H, W)}[args.workload],
                        "objects_per_gpu": B, "views_per_object": V, "image_size": H, "rotation_check": args.rotation_check,
+                       "inputs": "CPU meshes packed + copied every step" if args.host_meshes else "resident in HBM",
                        "parallelism": "objects sharded over %d GPU(s), no data-path collective" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -84,28 +84,34 @@ class PackedMeshes:
 
     @staticmethod
     def from_meshes(meshes, device, vert_colors=None):
+        """Pack on the host with numpy (zero-copy views of the CPU tensors; torch's CPU reductions cost tens of
+        milliseconds on small integer tensors), then one H2D copy per array."""
+        import numpy as np
         pairs = _mesh_pairs(meshes)
         if len(pairs) == 0:
             raise ValueError("empty mesh batch")
-        nv = [int(v.shape[0]) for v, _ in pairs]
-        nf = [int(f.shape[0]) for _, f in pairs]
+        vs = [np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v, dtype=np.float32).reshape(-1, 3) for v, _ in pairs]
+        fs = [np.asarray(f.detach().cpu().numpy() if torch.is_tensor(f) else f).reshape(-1, 3) for _, f in pairs]
+        nv = [int(v.shape[0]) for v in vs]
+        nf = [int(f.shape[0]) for f in fs]
         if min(nv) <= 0 or min(nf) <= 0:
             raise ValueError("every mesh needs at least one vertex and one face")
-        verts = torch.cat([v.reshape(-1, 3).to(torch.float32).cpu() for v, _ in pairs], 0)
-        faces = torch.cat([f.reshape(-1, 3).cpu() for _, f in pairs], 0)
-        if faces.numel() and (int(faces.min()) < 0 or any(int(f.max()) >= n for (_, f), n in zip(pairs, nv))):
-            raise ValueError("face index out of range")
-        faces = faces.to(torch.int32)
-        vo = torch.zeros(len(pairs) + 1, dtype=torch.int32)
-        fo = torch.zeros(len(pairs) + 1, dtype=torch.int32)
-        vo[1:] = torch.cumsum(torch.tensor(nv), 0)
-        fo[1:] = torch.cumsum(torch.tensor(nf), 0)
+        for f, n in zip(fs, nv):
+            if int(f.min()) < 0 or int(f.max()) >= n:
+                raise ValueError("face index out of range")
+        verts = torch.from_numpy(np.ascontiguousarray(np.concatenate(vs, 0)))
+        faces = torch.from_numpy(np.concatenate(fs, 0).astype(np.int32))
+        vo = np.zeros(len(pairs) + 1, np.int32)
+        fo = np.zeros(len(pairs) + 1, np.int32)
+        vo[1:] = np.cumsum(nv)
+        fo[1:] = np.cumsum(nf)
         vc = None
         if vert_colors is not None:  # (B, >=max Vn, 3) padded, as models/renderer.py:76-77 builds it
-            vc = torch.cat([vert_colors[b, :n].reshape(-1, 3).to(torch.float32).cpu() for b, n in enumerate(nv)], 0)
-            vc = vc.contiguous().to(device, non_blocking=True)
-        return PackedMeshes(verts.contiguous().to(device, non_blocking=True), faces.contiguous().to(device, non_blocking=True),
-                            vo.to(device, non_blocking=True), fo.to(device, non_blocking=True),
+            vcn = vert_colors.detach().cpu().numpy() if torch.is_tensor(vert_colors) else np.asarray(vert_colors)
+            vc = torch.from_numpy(np.ascontiguousarray(np.concatenate([vcn[b, :n].reshape(-1, 3) for b, n in enumerate(nv)], 0),
+                                                       dtype=np.float32)).to(device, non_blocking=True)
+        return PackedMeshes(verts.to(device, non_blocking=True), faces.to(device, non_blocking=True),
+                            torch.from_numpy(vo).to(device, non_blocking=True), torch.from_numpy(fo).to(device, non_blocking=True),
                             len(pairs), max(nv), max(nf), vc)
 
     def c_struct(self):
