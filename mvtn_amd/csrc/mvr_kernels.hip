@@ -227,16 +227,23 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_normals_accum(MeshPtrs m, long lo
 // atomics; same fixed-point sum as the 3-step global path, hence the same bits.
 #define MVR_NRM_BLOCK 1024
 #define MVR_NRM_LDS_VERTS 6400   // 6400 * 24 B = 150 KiB
-__device__ __forceinline__ void vattr_mesh_lds_body(const MeshPtrs &m, int b, unsigned char *smem, float4 *__restrict__ vattr,
-                                                    float *__restrict__ normals_out) {
+__device__ __forceinline__ void vattr_mesh_lds_body(const MeshPtrs &m, int b, int chunk, unsigned char *smem,
+                                                    float4 *__restrict__ vattr, float *__restrict__ normals_out) {
+  // the workgroup owns the vertices [vlo, vhi) of mesh b (a mesh with more than MVR_NRM_LDS_VERTS vertices is
+  // covered by several workgroups, each scanning all faces and keeping only the corners that fall in its range)
   unsigned long long *acc = (unsigned long long *)smem;
   const int f0 = m.face_off[b], nf = m.face_off[b + 1] - f0, v0 = m.vert_off[b], nv = m.vert_off[b + 1] - v0;
-  for (int i = threadIdx.x; i < 3 * nv; i += MVR_NRM_BLOCK) acc[i] = 0ull;
+  const int vlo = chunk * MVR_NRM_LDS_VERTS, vhi = min(nv, vlo + MVR_NRM_LDS_VERTS);
+  if (vlo >= nv) return;   // workgroup-uniform
+  const int nloc = vhi - vlo;
+  for (int i = threadIdx.x; i < 3 * nloc; i += MVR_NRM_BLOCK) acc[i] = 0ull;
   __syncthreads();
   const float lim = 1.0e9f;
   for (int f = threadIdx.x; f < nf; f += MVR_NRM_BLOCK) {
     const int32_t *fc = m.faces + 3 * (size_t)(f0 + f);
     int i0 = fc[0], i1 = fc[1], i2 = fc[2];
+    const bool in0 = i0 >= vlo && i0 < vhi, in1 = i1 >= vlo && i1 < vhi, in2 = i2 >= vlo && i2 < vhi;
+    if (!(in0 || in1 || in2)) continue;
     const float *pa = m.verts + 3 * (size_t)(v0 + i0), *pb = m.verts + 3 * (size_t)(v0 + i1), *pc = m.verts + 3 * (size_t)(v0 + i2);
     f3 e0 = {pc[0] - pb[0], pc[1] - pb[1], pc[2] - pb[2]};
     f3 e1 = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
@@ -244,27 +251,27 @@ __device__ __forceinline__ void vattr_mesh_lds_body(const MeshPtrs &m, int b, un
     unsigned long long qx = (unsigned long long)__float2ll_rn(fminf(fmaxf(n.x, -lim), lim) * MVR_FIX_SCALE);
     unsigned long long qy = (unsigned long long)__float2ll_rn(fminf(fmaxf(n.y, -lim), lim) * MVR_FIX_SCALE);
     unsigned long long qz = (unsigned long long)__float2ll_rn(fminf(fmaxf(n.z, -lim), lim) * MVR_FIX_SCALE);
-    atomicAdd(acc + 3 * i0, qx); atomicAdd(acc + 3 * i0 + 1, qy); atomicAdd(acc + 3 * i0 + 2, qz);
-    atomicAdd(acc + 3 * i1, qx); atomicAdd(acc + 3 * i1 + 1, qy); atomicAdd(acc + 3 * i1 + 2, qz);
-    atomicAdd(acc + 3 * i2, qx); atomicAdd(acc + 3 * i2 + 1, qy); atomicAdd(acc + 3 * i2 + 2, qz);
+    if (in0) { atomicAdd(acc + 3 * (i0 - vlo), qx); atomicAdd(acc + 3 * (i0 - vlo) + 1, qy); atomicAdd(acc + 3 * (i0 - vlo) + 2, qz); }
+    if (in1) { atomicAdd(acc + 3 * (i1 - vlo), qx); atomicAdd(acc + 3 * (i1 - vlo) + 1, qy); atomicAdd(acc + 3 * (i1 - vlo) + 2, qz); }
+    if (in2) { atomicAdd(acc + 3 * (i2 - vlo), qx); atomicAdd(acc + 3 * (i2 - vlo) + 1, qy); atomicAdd(acc + 3 * (i2 - vlo) + 2, qz); }
   }
   __syncthreads();
   const double inv = 1.0 / 4294967296.0;
-  for (int i = threadIdx.x; i < nv; i += MVR_NRM_BLOCK) {
+  for (int i = threadIdx.x; i < nloc; i += MVR_NRM_BLOCK) {
     f3 a = {(float)((double)(long long)acc[3 * i] * inv), (float)((double)(long long)acc[3 * i + 1] * inv),
             (float)((double)(long long)acc[3 * i + 2] * inv)};
     f3 n = mvr::normalize<float>(a, mvr::kNormalizeEps);
-    size_t v = (size_t)v0 + i;
+    size_t v = (size_t)v0 + vlo + i;
     vattr[2 * v] = make_float4(m.verts[3 * v], m.verts[3 * v + 1], m.verts[3 * v + 2], 0.f);
     vattr[2 * v + 1] = make_float4(n.x, n.y, n.z, 0.f);
     if (normals_out) { normals_out[3 * v] = n.x; normals_out[3 * v + 1] = n.y; normals_out[3 * v + 2] = n.z; }
   }
 }
 
-__global__ void __launch_bounds__(MVR_NRM_BLOCK) k_vattr_mesh_lds(MeshPtrs m, float4 *__restrict__ vattr,
+__global__ void __launch_bounds__(MVR_NRM_BLOCK) k_vattr_mesh_lds(MeshPtrs m, int chunks, float4 *__restrict__ vattr,
                                                                   float *__restrict__ normals_out) {
   extern __shared__ __align__(16) unsigned char smem[];
-  vattr_mesh_lds_body(m, blockIdx.x, smem, vattr, normals_out);
+  vattr_mesh_lds_body(m, blockIdx.x / chunks, blockIdx.x % chunks, smem, vattr, normals_out);
 }
 
 // one lane per vertex: normalise the accumulated normal (eps 1e-6) and store the position beside it.
@@ -443,13 +450,14 @@ __global__ void __launch_bounds__(MVR_PB_BLOCK) k_project_bins_view(MeshPtrs m, 
 // Pre-pass in ONE launch: workgroups [0, B) build the per-mesh vertex attributes (position + normal), workgroups
 // [B, B + N) project one view each and bin its faces.  The two halves are independent, so they simply run
 // concurrently on different CUs (no second stream, no event round trips between queues).
-__global__ void __launch_bounds__(1024) k_mesh_prepass(MeshPtrs m, int V, int H, int W, int G, int stride, int cull_backfaces,
-                                                      const float *__restrict__ R, const float *__restrict__ T, float s,
-                                                      float4 *__restrict__ proj_all, unsigned short *__restrict__ bins,
-                                                      float4 *__restrict__ vattr) {
+__global__ void __launch_bounds__(1024) k_mesh_prepass(MeshPtrs m, int chunks, int V, int H, int W, int G, int stride,
+                                                      int cull_backfaces, const float *__restrict__ R,
+                                                      const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
+                                                      unsigned short *__restrict__ bins, float4 *__restrict__ vattr) {
   extern __shared__ __align__(16) unsigned char smem[];
-  if ((int)blockIdx.x < m.B) vattr_mesh_lds_body(m, blockIdx.x, smem, vattr, nullptr);
-  else project_bins_view_body(m, (int)blockIdx.x - m.B, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins);
+  const int nb_attr = m.B * chunks;
+  if ((int)blockIdx.x < nb_attr) vattr_mesh_lds_body(m, blockIdx.x / chunks, blockIdx.x % chunks, smem, vattr, nullptr);
+  else project_bins_view_body(m, (int)blockIdx.x - nb_attr, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins);
 }
 
 struct RasterArgs {
@@ -1396,11 +1404,12 @@ size_t mvr_mesh_workspace_bytes(const mvr_mesh_batch *meshes, const mvr_mesh_par
 static int launch_vattr(const mvr_mesh_batch *m, const MeshWs &ws, float *normals_out, hipStream_t st) {
   MeshPtrs mp = {m->verts, m->faces, m->vert_off, m->face_off, m->vert_colors, m->n_meshes};
   const int max_verts = m->max_verts > 0 ? m->max_verts : m->total_verts;
-  if (max_verts <= MVR_NRM_LDS_VERTS) {
-    size_t lds = (size_t)3 * max_verts * sizeof(unsigned long long);
+  const int chunks = (max_verts + MVR_NRM_LDS_VERTS - 1) / MVR_NRM_LDS_VERTS;
+  if (chunks <= 16) {   // beyond that every workgroup would rescan all faces 16+ times: use the global-atomic path
+    size_t lds = (size_t)3 * (max_verts < MVR_NRM_LDS_VERTS ? max_verts : MVR_NRM_LDS_VERTS) * sizeof(unsigned long long);
     if (lds > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void *)k_vattr_mesh_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_vattr_mesh_lds, dim3(m->n_meshes), dim3(MVR_NRM_BLOCK), lds, st, mp, ws.vattr, normals_out);
+    hipLaunchKernelGGL(k_vattr_mesh_lds, dim3(m->n_meshes * chunks), dim3(MVR_NRM_BLOCK), lds, st, mp, chunks, ws.vattr, normals_out);
     return hip_check(hipGetLastError(), "k_vattr_mesh_lds");
   }
   HIP_TRY(hipMemsetAsync(ws.nacc, 0, (size_t)3 * m->total_verts * sizeof(long long), st));
@@ -1441,13 +1450,16 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   const int max_faces = meshes->max_faces > 0 ? meshes->max_faces : meshes->total_faces;
   const int G = bin_rows_for(H, TH);
   const int cullf = (params->flags & MVR_CULL_BACKFACES) ? 1 : 0;
-  if (max_verts <= MVR_NRM_LDS_VERTS && max_verts <= MVR_PB_LDS_VERTS) {
+  if (max_verts <= MVR_PB_LDS_VERTS) {
     // one pre-pass launch: per-mesh vertex attributes + per-view projection/binning side by side
-    const size_t lds_pp = (size_t)3 * max_verts * sizeof(unsigned long long);   // >= the 12 B/vertex the projection half needs
+    const int chunks = (max_verts + MVR_NRM_LDS_VERTS - 1) / MVR_NRM_LDS_VERTS;
+    const size_t lds_attr = (size_t)3 * (max_verts < MVR_NRM_LDS_VERTS ? max_verts : MVR_NRM_LDS_VERTS) * sizeof(unsigned long long);
+    const size_t lds_proj = (size_t)3 * max_verts * sizeof(float);
+    const size_t lds_pp = lds_attr > lds_proj ? lds_attr : lds_proj;
     if (lds_pp > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp));
-    hipLaunchKernelGGL(k_mesh_prepass, dim3(meshes->n_meshes + N), dim3(1024), lds_pp, st, mp, V, H, W, G, ws.bin_stride, cullf, R, T,
-                       s, ws.proj, ws.bins, ws.vattr);
+    hipLaunchKernelGGL(k_mesh_prepass, dim3(meshes->n_meshes * chunks + N), dim3(1024), lds_pp, st, mp, chunks, V, H, W, G,
+                       ws.bin_stride, cullf, R, T, s, ws.proj, ws.bins, ws.vattr);
     HIP_TRY(hipGetLastError());
   } else {
     rc = launch_vattr(meshes, ws, nullptr, st);
