@@ -70,10 +70,15 @@ def load():
     if _LIB is not None:
         return _LIB
     path = lib_path()
+    if not os.path.exists(path) and not os.environ.get("MVR_LIB"):
+        try:  # the in-tree library has not been built yet: compile it now (hipcc cross-compiles without a GPU)
+            _build.build_hip()
+        except Exception as e:  # noqa: BLE001
+            raise ImportError(
+                "mvtn_amd: %s is missing and could not be built (%s) — the HIP extension is the only rendering path "
+                "(no CPU fallback).  Build it with `python -c 'import __graft_entry__ as g; g.build()'`." % (path, e))
     if not os.path.exists(path):
-        raise ImportError(
-            "mvtn_amd: %s is missing — the HIP extension is the only rendering path (no CPU fallback). "
-            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `python -m mvtn_amd.build`." % path)
+        raise ImportError("mvtn_amd: %s does not exist" % path)
     lib = ctypes.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

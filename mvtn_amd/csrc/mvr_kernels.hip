@@ -38,6 +38,12 @@ typedef V3<float> f3;
 #define MVR_LIST_CAP 1536       // LDS face list (4 B entries); a strip touched by more faces is processed in windows of this size
 #define MVR_BATCH 256           // faces set up / rasterised per batch (one per lane in the setup phase)
 #define MVR_V3_ROUNDS 4          // scan: 8 faces per lane per round -> 256 * 8 * 4 = 8192 faces per pass
+#ifndef MVR_RB
+#define MVR_RB 256               // threads per rasteriser workgroup
+#endif
+#define MVR_RW (MVR_RB / 64)
+#define MVR_RBATCH MVR_RB        // faces set up per batch: one per lane
+#define MVR_RB_WAVES_PER_SIMD 4
 #define MVR_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define MVR_NACC 18
 
@@ -584,16 +590,16 @@ __device__ __forceinline__ void unpack_face(const FaceCoef &q, mvr::FaceSetup<fl
 //              the prefix sums) -> no lane waits for another lane's big triangle; any face size is handled by
 //              the same loop.  Depth resolve: 64-bit LDS atomicMin on (float_bits(z) << 32 | face).
 //   shade    : every pixel of the strip: winner -> barycentrics -> Phong + hard blend -> planar store.
-__global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a) {
+__global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_shade(RasterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int W = a.W, H = a.H, TH = a.TH;
   unsigned long long *keys = (unsigned long long *)smem;                       // TH * W
-  FaceCoef *coef = (FaceCoef *)(keys + (size_t)TH * W);                        // MVR_BATCH
-  int2 *rng = (int2 *)(coef + MVR_BATCH);                                      // MVR_BATCH: x0|x1<<16 , y0|y1<<16
-  int *cum = (int *)(rng + MVR_BATCH);                                         // MVR_BATCH + 1 exclusive prefix sums
-  int *list = cum + (MVR_BATCH + 1);                                           // MVR_LIST_CAP face indices
+  FaceCoef *coef = (FaceCoef *)(keys + (size_t)TH * W);                        // MVR_RBATCH
+  int2 *rng = (int2 *)(coef + MVR_RBATCH);                                      // MVR_RBATCH: x0|x1<<16 , y0|y1<<16
+  int *cum = (int *)(rng + MVR_RBATCH);                                         // MVR_RBATCH + 1 exclusive prefix sums
+  int *list = cum + (MVR_RBATCH + 1);                                           // MVR_LIST_CAP face indices
   int *cnt = list + MVR_LIST_CAP;                                              // [0] list entries, [1..4] wave totals
-  __shared__ int start[MVR_BLOCK];                                             // first face of every lane's run
+  __shared__ int start[MVR_RB];                                             // first face of every lane's run
 
   int n, strip;
   decode_block(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
@@ -622,22 +628,22 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
   unsigned long long t_scan = 0, t_small = 0, t_large = 0, n_small_tot = 0, n_large_tot = 0;
   unsigned long long tc0 = clock64();
 #endif
-  const int faces_per_pass = MVR_BLOCK * 8 * MVR_V3_ROUNDS;
+  const int faces_per_pass = MVR_RB * 8 * MVR_V3_ROUNDS;
   for (int pbase = 0; pbase < nf; pbase += faces_per_pass) {
     // ---- scan: the row-bin vectors of up to 8192 faces are requested up front (4 x 16 B per lane); hit masks
     //      stay in registers; one wave prefix sum + ONE LDS atomic per wave orders the hits ---------------------
     uint4 q[MVR_V3_ROUNDS];
 #pragma unroll
     for (int r = 0; r < MVR_V3_ROUNDS; ++r) {
-      const int f0 = pbase + (r * MVR_BLOCK + tid) * 8;
+      const int f0 = pbase + (r * MVR_RB + tid) * 8;
       q[r] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
       if (f0 < nf) q[r] = *reinterpret_cast<const uint4 *>(bins + f0);
     }
-    if (pbase == 0) for (int i = tid; i < rows * W; i += MVR_BLOCK) keys[i] = MVR_KEY_EMPTY;   // under the loads' latency
+    if (pbase == 0) for (int i = tid; i < rows * W; i += MVR_RB) keys[i] = MVR_KEY_EMPTY;   // under the loads' latency
     unsigned mask = 0;   // bit (8 r + k): face pbase + (r * BLOCK + tid) * 8 + k touches this strip
 #pragma unroll
     for (int r = 0; r < MVR_V3_ROUNDS; ++r) {
-      const int f0 = pbase + (r * MVR_BLOCK + tid) * 8;
+      const int f0 = pbase + (r * MVR_RB + tid) * 8;
       const unsigned w[4] = {q[r].x, q[r].y, q[r].z, q[r].w};
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -666,7 +672,7 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
       while (m) {
         const int bit = __ffs(m) - 1;
         m &= m - 1;
-        if (pos >= 0 && pos < MVR_LIST_CAP) list[pos] = pbase + ((bit >> 3) * MVR_BLOCK + tid) * 8 + (bit & 7);
+        if (pos >= 0 && pos < MVR_LIST_CAP) list[pos] = pbase + ((bit >> 3) * MVR_RB + tid) * 8 + (bit & 7);
         ++pos;
       }
     }
@@ -676,8 +682,8 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
     unsigned long long tc1 = clock64();
     t_scan += tc1 - tc0; n_small_tot += n_list;
 #endif
-    for (int b0 = 0; b0 < n_list; b0 += MVR_BATCH) {
-      const int nb = min(MVR_BATCH, n_list - b0);
+    for (int b0 = 0; b0 < n_list; b0 += MVR_RBATCH) {
+      const int nb = min(MVR_RBATCH, n_list - b0);
 #ifdef MVR_DIAG
       unsigned long long ts0 = clock64();
 #endif
@@ -706,26 +712,26 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
       __syncthreads();
       int wave_off = 0, total = 0;
 #pragma unroll
-      for (int w = 0; w < MVR_WAVES; ++w) {
+      for (int w = 0; w < MVR_RW; ++w) {
         int t = cnt[1 + w];
         if (w < wave) wave_off += t;
         total += t;
       }
       cum[tid] = wave_off + incl - my_cnt;
-      if (tid == 0) cum[MVR_BATCH] = total;
+      if (tid == 0) cum[MVR_RBATCH] = total;
       __syncthreads();
 #ifdef MVR_DIAG
       unsigned long long ts1 = clock64();
       t_small += ts1 - ts0; n_large_tot += total;
 #endif
       // ---- raster: balanced split of the batch's `total` (face, pixel) candidates over 256 lanes -------
-      const int quota = (total + MVR_BLOCK - 1) / MVR_BLOCK;
+      const int quota = (total + MVR_RB - 1) / MVR_RB;
       // face e owns the lanes whose run starts inside [cum[e], cum[e] + my_cnt): lanes ceil(cum[e]/quota) ... ;
       // it writes its own index into start[] for them (no dependent LDS chain, unlike a binary search per lane)
       if (my_cnt > 0) {
         const int c0 = wave_off + incl - my_cnt;
         int l0 = (c0 + quota - 1) / quota, l1 = (c0 + my_cnt - 1) / quota;
-        if (l1 > MVR_BLOCK - 1) l1 = MVR_BLOCK - 1;
+        if (l1 > MVR_RB - 1) l1 = MVR_RB - 1;
         for (int l = l0; l <= l1; ++l) start[l] = tid;
       }
       __syncthreads();
@@ -817,14 +823,14 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
   }
 
   int *plist = (int *)coef;                       // the batch records are dead now: reuse their LDS
-  const int plist_cap = (int)((sizeof(FaceCoef) + sizeof(int2)) * MVR_BATCH / sizeof(int));
+  const int plist_cap = (int)((sizeof(FaceCoef) + sizeof(int2)) * MVR_RBATCH / sizeof(int));
   const int n_pix = rows * W;
   if (tid == 0) cnt[0] = 0;
   __syncthreads();
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
   for (int pbase = 0; pbase < n_pix; pbase += plist_cap) {
     const int pend = min(n_pix, pbase + plist_cap);
-    for (int p0 = pbase; p0 < pend; p0 += MVR_BLOCK) {   // uniform trip count: ballots need every lane
+    for (int p0 = pbase; p0 < pend; p0 += MVR_RB) {   // uniform trip count: ballots need every lane
       const int pix = p0 + tid;
       const bool in = pix < pend;
       const bool covered = in && keys[in ? pix : 0] != MVR_KEY_EMPTY;
@@ -862,7 +868,7 @@ __global__ void __launch_bounds__(MVR_BLOCK, 4) k_mesh_raster_shade(RasterArgs a
         c2 = {sh.vcol[3 * i2], sh.vcol[3 * i2 + 1], sh.vcol[3 * i2 + 2]};
       }
       const int cur_pix = pix, cur_face = face, ci0 = i0, ci1 = i1, ci2 = i2;
-      e += MVR_BLOCK;
+      e += MVR_RB;
       if (e < n_cov) {  // prefetch the next pixel's indices
         pix = plist[e];
         face = (int)(unsigned)(keys[pix] & 0xffffffffull);
@@ -1489,15 +1495,15 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   a.n_light = params->n_light; a.flags = params->flags; a.s = s;
   a.ambient = params->ambient; a.diffuse = params->diffuse; a.specular = params->specular; a.shininess = params->shininess;
   for (int k = 0; k < 3; ++k) { a.obj[k] = params->obj_color[k]; a.bg[k] = params->bg_color[k]; }
-  size_t lds = (size_t)TH * W * 8 + (size_t)MVR_BATCH * (sizeof(FaceCoef) + sizeof(int2)) + (size_t)(MVR_BATCH + 1) * 4 +
-               (size_t)MVR_LIST_CAP * 4 + 8 * 4;
+  size_t lds = (size_t)TH * W * 8 + (size_t)MVR_RBATCH * (sizeof(FaceCoef) + sizeof(int2)) + (size_t)(MVR_RBATCH + 1) * 4 +
+               (size_t)MVR_LIST_CAP * 4 + 16 * 4;
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_raster_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int grid = 8 * a.views_per_xcd * n_strips;
   {
     ProfScope prof(PROF_MESH_FWD, st);
-    hipLaunchKernelGGL(k_mesh_raster_shade, dim3(grid), dim3(MVR_BLOCK), lds, st, a);
+    hipLaunchKernelGGL(k_mesh_raster_shade, dim3(grid), dim3(MVR_RB), lds, st, a);
   }
   return hip_check(hipGetLastError(), "k_mesh_raster_shade");
 }
