@@ -11,6 +11,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* threads used by the literal pixel-major loops (mode 0); 1 = faithful single-threaded stand-in */
+static int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n > 1 ? n : 1; }
+
 #define REAL float
 #define SUFFIX _f32
 #define SQRT_FN sqrtf

@@ -38,6 +38,12 @@ def lib():
     return _LIB
 
 
+def set_threads(n):
+    """Threads of the literal pixel-major loops (mode 0).  1 (default) is the faithful stand-in for PyTorch3D's
+    single-threaded CPU rasteriser; > 1 only for bench.py's "all host cores" line."""
+    lib().orc_set_threads(ctypes.c_int(int(n)))
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
