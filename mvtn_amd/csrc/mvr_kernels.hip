@@ -1320,6 +1320,8 @@ static int check_mesh_args(const mvr_mesh_batch *m, const mvr_mesh_params *p) {
   if (!m->verts || !m->faces || !m->vert_off || !m->face_off) return set_err(MVR_ERR_INVALID_ARG, "null mesh pointer");
   if (p->n_views <= 0 || p->image_h <= 0 || p->image_w <= 0) return set_err(MVR_ERR_INVALID_ARG, "bad view count / image size");
   if (p->image_h > 32767 || p->image_w > 32767) return set_err(MVR_ERR_UNSUPPORTED, "image side > 32767");
+  if (p->image_h != p->image_w)  // MVTN only renders square images (models/renderer.py:90); PyTorch3D's non-square NDC rule differs
+    return set_err(MVR_ERR_UNSUPPORTED, "non-square images are not supported");
   size_t N = (size_t)m->n_meshes * p->n_views;
   if (p->n_light != 1 && (size_t)p->n_light != N) return set_err(MVR_ERR_INVALID_ARG, "n_light must be 1 or B*V");
   return MVR_OK;
@@ -1589,6 +1591,7 @@ static int check_points_args(const mvr_points_params *p) {
     return set_err(MVR_ERR_INVALID_ARG, "bad points params");
   if (!(p->radius > 0.0)) return set_err(MVR_ERR_INVALID_ARG, "radius must be > 0");
   if (p->image_h > 32767 || p->image_w > 32767) return set_err(MVR_ERR_UNSUPPORTED, "image side > 32767");
+  if (p->image_h != p->image_w) return set_err(MVR_ERR_UNSUPPORTED, "non-square images are not supported");
   return MVR_OK;
 }
 

@@ -212,3 +212,13 @@ def test_view_selectors_match_reference(golden):
     assert not torch.equal(a1, a2) and a1.shape == (2, 12)
     with pytest.raises(NotImplementedError):
         view_selector("learned_spherical", 12)
+
+
+def test_non_square_images_are_rejected_without_gpu():
+    from mvtn_amd import _lib
+    lib = _lib.load()
+    dummy = ctypes.c_void_p(16)  # never dereferenced: the size check comes first
+    mb = _lib.MeshBatch(1, 3, 1, 1, 3, 0, 16, 16, 16, 16, None)
+    mp = _lib.MeshParams(1, 8, 9, 0, 1, 0, 60.0, 0.5, 0.3, 0.2, 64.0)
+    assert lib.mvr_render_meshes_forward(mb, mp, dummy, dummy, dummy, dummy, None, dummy, 1 << 20, None) == 4
+    assert b"non-square" in lib.mvr_last_error()

@@ -49,7 +49,7 @@ tot = (d[:, 2] - d[:, 0]).astype(np.float64)
 print("workgroups: %d   cycles/workgroup (s_memtime ticks @100MHz?): mean %.0f  max %.0f" % (len(d), tot.mean(), tot.max()))
 print("  raster loop total  : %5.1f %%" % (100 * (d[:, 1] - d[:, 0]).sum() / tot.sum()))
 print("    scan             : %5.1f %%" % (100 * d[:, 3].sum() / tot.sum()))
-print("    small faces      : %5.1f %%" % (100 * d[:, 4].sum() / tot.sum()))
-print("    large faces      : %5.1f %%" % (100 * d[:, 5].sum() / tot.sum()))
+print("    setup + prefix   : %5.1f %%" % (100 * d[:, 4].sum() / tot.sum()))
+print("    candidate loop   : %5.1f %%" % (100 * d[:, 5].sum() / tot.sum()))
 print("  shade + store      : %5.1f %%" % (100 * (d[:, 2] - d[:, 1]).sum() / tot.sum()))
-print("  faces per workgroup: small mean %.1f max %d | large mean %.1f max %d" % (d[:, 6].mean(), d[:, 6].max(), d[:, 7].mean(), d[:, 7].max()))
+print("  per workgroup: listed faces mean %.1f max %d | candidates mean %.1f max %d" % (d[:, 6].mean(), d[:, 6].max(), d[:, 7].mean(), d[:, 7].max()))
