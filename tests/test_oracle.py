@@ -223,3 +223,23 @@ def test_points_scale_by_inverse_distance(oracle):
     b = oracle.render_points(pts, [[30.0]], [[10.0]], [[2.0]], 64, radius=0.04)
     ca, cb = (a["idx"] >= 0).sum(), (b["idx"] >= 0).sum()
     assert 0.2 < cb / ca < 0.45  # ~ (1/2)^2 of the covered area, thickened by the fixed radius
+
+
+def test_oracle_regression_fixture():
+    """The oracle's own output on C1 is frozen (hashes of the integer / exactly-rounded fields, sums of the images):
+    guards the checker against drift between rounds.  Not a reference vector — see tests/golden/make_oracle_regression.py."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_regression", os.path.join(here, "make_oracle_regression.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    got = mod.compute()
+    want = json.load(open(os.path.join(here, "oracle_regression.json")))
+    for part in ("mesh_c1", "points"):
+        for k, v in want[part].items():
+            if k.endswith("sha256") or k == "covered":
+                assert got[part][k] == v, (part, k)
+            else:
+                assert abs(got[part][k] - v) <= 1e-6 * max(1.0, abs(v)), (part, k)
