@@ -153,8 +153,9 @@ def render_meshes(verts_list, faces_list, azim, elev, dist, image_size, light_di
 
 def render_points(points, azim, elev, dist, image_size, radius=0.006, obj_color=(1.0, 1.0, 1.0),
                   bg_color=(1.0, 1.0, 1.0), point_colors=None, mode=1, fixed_idx=None,
-                  dtype=np.float32, R=None, T=None, return_fragments=True):
-    """Restates models/renderer.py:116-151.  points (B,P,3); azim/elev/dist (B,V)."""
+                  dtype=np.float32, R=None, T=None, return_fragments=True, points_per_pixel=1):
+    """Restates models/renderer.py:116-151.  points (B,P,3); azim/elev/dist (B,V).  idx / zbuf / dist2 are
+    (N,H,W) for points_per_pixel == 1 and (N,H,W,K) otherwise."""
     sfx, cty = _sfx(dtype)
     azim = np.asarray(azim, dtype)
     B, V = azim.shape
@@ -173,12 +174,14 @@ def render_points(points, azim, elev, dist, image_size, radius=0.006, obj_color=
     oc = _flat(obj_color, dtype)
     bg = _flat(bg_color, dtype)
     images = np.empty((B, V, 3, H, W), dtype)
-    idx = np.empty((N, H, W), np.int32) if return_fragments else None
-    zbuf = np.empty((N, H, W), dtype) if return_fragments else None
-    d2 = np.empty((N, H, W), dtype) if return_fragments else None
+    K = int(points_per_pixel)
+    shp = (N, H, W) if K == 1 else (N, H, W, K)
+    idx = np.empty(shp, np.int32) if return_fragments else None
+    zbuf = np.empty(shp, dtype) if return_fragments else None
+    d2 = np.empty(shp, dtype) if return_fragments else None
     fixed = None if fixed_idx is None else np.ascontiguousarray(fixed_idx, np.int32)
     getattr(lib(), "orc_render_points" + sfx)(
-        ctypes.c_int(B), ctypes.c_int(V), ctypes.c_int(P), ctypes.c_int(H), ctypes.c_int(W),
+        ctypes.c_int(B), ctypes.c_int(V), ctypes.c_int(P), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(K),
         _ptr(pts), _ptr(R), _ptr(T), _ptr(d), _ptr(pc), _ptr(oc), _ptr(bg),
         ctypes.c_double(radius), ctypes.c_int(mode), _ptr(fixed),
         _ptr(images), _ptr(idx), _ptr(zbuf), _ptr(d2))

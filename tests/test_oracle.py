@@ -243,3 +243,31 @@ def test_oracle_regression_fixture():
                 assert got[part][k] == v, (part, k)
             else:
                 assert abs(got[part][k] - v) <= 1e-6 * max(1.0, abs(v)), (part, k)
+
+
+def test_points_topk(oracle):
+    """points_per_pixel = K: slot 0 equals the K = 1 result, slots ascend in (z, index), both loop orders agree,
+    and with a constant colour the norm-weighted sum returns that colour (up to the 1e-4 clamp)."""
+    v, f = syn.synthetic_mesh("S", 2)
+    pts = syn.surface_points(v, f, 1500, 1)[None]
+    az, el, di = [[15.0, 140.0]], [[25.0, -35.0]], [[1.0, 1.2]]
+    col = np.random.default_rng(0).uniform(0, 1, (1, 1500, 3)).astype(np.float32)
+    one = oracle.render_points(pts, az, el, di, 64, radius=0.05, point_colors=col)
+    a = oracle.render_points(pts, az, el, di, 64, radius=0.05, point_colors=col, points_per_pixel=4, mode=0)
+    b = oracle.render_points(pts, az, el, di, 64, radius=0.05, point_colors=col, points_per_pixel=4, mode=1)
+    for k in ("images", "idx", "zbuf", "dist2"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["idx"][..., 0], one["idx"]) and np.array_equal(a["zbuf"][..., 0], one["zbuf"])
+    z = a["zbuf"]
+    valid = a["idx"] >= 0
+    assert (valid[..., 1:] <= valid[..., :-1]).all()                      # empty slots only at the end
+    both = valid[..., 1:] & valid[..., :-1]
+    assert (z[..., 1:][both] >= z[..., :-1][both]).all()
+    assert (a["idx"][..., 1] >= 0).mean() > 0.05                          # the test actually has depth complexity
+    assert not np.array_equal(a["images"], one["images"])                  # different colours mix
+    c = oracle.render_points(pts, az, el, di, 64, radius=0.05, obj_color=(0.3, 0.6, 0.9), bg_color=(0, 0, 0), points_per_pixel=4)
+    cov = c["idx"][..., 0] >= 0
+    w = np.where(c["idx"] >= 0, 1 - c["dist2"] / np.float32(0.05 * 0.05), 0).sum(-1)
+    ok = cov & (w > 1e-3)
+    img = c["images"].reshape(2, 3, 64, 64)
+    assert np.abs(img[:, 0][ok] - 0.3).max() < 1e-5 and np.abs(img[:, 2][ok] - 0.9).max() < 1e-5
