@@ -84,6 +84,8 @@ typedef struct mvr_points_params {
   int32_t n_views;        /* V */
   int32_t image_h, image_w;
   int32_t strip_rows;     /* 0 = default */
+  int32_t points_per_pixel; /* K of PointsRasterizationSettings(points_per_pixel), :132; 0 means 1; <= 150 */
+  int32_t reserved_;      /* explicit padding before the double; must be 0 */
   double radius;          /* PointsRasterizationSettings(radius), :131 — double: the compositor weight
                              1 - d2/(r*r) uses r*r evaluated in double then rounded (models/renderer.py:135-145
                              -> PointsRenderer), the rasteriser uses float(r)^2 */
@@ -174,16 +176,18 @@ int mvr_render_meshes_backward(const mvr_mesh_batch *meshes, const mvr_mesh_para
 size_t mvr_points_workspace_bytes(const mvr_points_params *params);
 
 /* Pointclouds.extend(V).scale_(1/dist) -> OpenGLOrthographicCameras(R,T) ->
- * PointsRasterizer(radius, points_per_pixel=1) -> NormWeightedCompositor(background).
+ * PointsRasterizer(radius, points_per_pixel=K) -> NormWeightedCompositor(background).
  *   points (B,P,3); point_colors (B,P,3) or NULL (constant obj_color); dist (N);
- *   images (B,V,3,H,W) out; pix_to_point (N,H,W) out or NULL (LOCAL point index, -1 empty). */
+ *   images (B,V,3,H,W) out; pix_to_point (N,H,W,K) out or NULL: LOCAL point indices of the K nearest
+ *   points of the pixel in ascending (z, index), -1 = empty slot (empties are at the end). */
 int mvr_render_points_forward(const mvr_points_params *params, const float *points,
                               const float *point_colors, const float *R, const float *T,
                               const float *dist, float *images, int32_t *pix_to_point,
                               void *workspace, size_t workspace_bytes, mvr_stream_t stream);
 
-/* backward w.r.t. cameras and dist.  With points_per_pixel = 1 the compositor's gradient
- * vanishes except where the weight clamp max(w, 1e-4) is active. */
+/* backward w.r.t. cameras and dist.  The compositor's weight gradient is PyTorch3D's
+ * (f_k S - sum_j w_j f_j) / S^2 with S = max(sum_j w_j, 1e-4): with points_per_pixel = 1 it is exactly
+ * zero except where the clamp is active.  pix_to_point is the forward's (N,H,W,K). */
 int mvr_render_points_backward(const mvr_points_params *params, const float *points,
                                const float *point_colors, const float *R, const float *T,
                                const float *dist, const int32_t *pix_to_point,

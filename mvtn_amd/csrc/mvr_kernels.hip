@@ -1178,13 +1178,118 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_points_raster_shade(PointsArgs a)
   }
 }
 
+// points_per_pixel = K > 1 (PointsRasterizationSettings.points_per_pixel, models/renderer.py:129-133; the reference's
+// default is 1 and takes k_points_raster_shade above).  The K nearest points of every pixel in ascending (z, index)
+// are found by K min-passes over the strip: pass k keeps, per pixel, the smallest key that is >= lo[pix], where lo
+// is one past the key chosen by pass k-1 (keys are unique per point, so ties in z are enumerated by index exactly
+// as a sort by (z, index) would).  The slots are written to idx_out (N,H,W,K) as they are found, then composed
+// NormWeightedCompositor-style in slot order: out_c = sum_k (f_ck w_k) / max(sum_k w_k, 1e-4).
+__global__ void __launch_bounds__(MVR_BLOCK) k_points_raster_topk(PointsArgs a, int K, int32_t *__restrict__ idx_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int W = a.W, H = a.H, TH = a.TH;
+  unsigned long long *keys = (unsigned long long *)smem;
+  unsigned long long *lo = keys + (size_t)TH * W;
+  float *px_tab = (float *)(lo + (size_t)TH * W);
+  float *py_tab = px_tab + W;
+  int n, strip;
+  decode_block(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
+  if (n >= a.N) return;
+  const int tid = threadIdx.x;
+  const int b = n / a.V;
+  const int r0 = strip * TH;
+  const int rows = min(TH, H - r0);
+  const int jy_hi = H - 1 - r0, jy_lo = jy_hi - (rows - 1);
+  const unsigned g_lo = (unsigned)(r0 / a.bin_rows), g_hi = (unsigned)((r0 + rows - 1) / a.bin_rows);
+  for (int i = tid; i < rows * W; i += MVR_BLOCK) lo[i] = 0ull;
+  for (int i = tid; i < W; i += MVR_BLOCK) px_tab[i] = mvr::pix_to_ndc<float>(i, W);
+  for (int i = tid; i < rows; i += MVR_BLOCK) py_tab[i] = mvr::pix_to_ndc<float>(jy_lo + i, H);
+  const float4 *__restrict__ pv = a.pv + (size_t)n * a.pstride;
+  const unsigned short *__restrict__ pbin = a.pbin + (size_t)n * a.pstride;
+  const size_t HW = (size_t)H * W;
+  int32_t *slots = idx_out + ((size_t)n * HW + (size_t)r0 * W) * K;
+  int k_done = 0;
+  for (int k = 0; k < K; ++k) {
+    for (int i = tid; i < rows * W; i += MVR_BLOCK) keys[i] = MVR_KEY_EMPTY;
+    __syncthreads();
+    for (int p0 = tid * 4; p0 < a.P; p0 += MVR_BLOCK * 4) {
+      const uint2 qb = *reinterpret_cast<const uint2 *>(pbin + p0);
+      const unsigned w[2] = {qb.x, qb.y};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned e = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+        const int p = p0 + j;
+        if (e == MVR_BIN_NONE || (e & 0xffu) > g_hi || (e >> 8) < g_lo || p >= a.P) continue;
+        const float4 q = pv[p];
+        const unsigned long long key = ((unsigned long long)__float_as_uint(q.z + 0.0f) << 32) | (unsigned)p;
+        int x0, x1, y0, y1;
+        ndc_range(q.x - a.radius, q.x + a.radius, W, &x0, &x1);
+        ndc_range(q.y - a.radius, q.y + a.radius, H, &y0, &y1);
+        y0 = max(y0, jy_lo); y1 = min(y1, jy_hi);
+        for (int jy = y0; jy <= y1; ++jy) {
+          const float dy = q.y - py_tab[jy - jy_lo];
+          const size_t rbase = (size_t)(jy_hi - jy) * W + (W - 1);
+          for (int ix = x0; ix <= x1; ++ix) {
+            const float dx = q.x - px_tab[ix];
+            const float dd = dx * dx + dy * dy;
+            if (dd < a.r2 && key >= lo[rbase - ix]) atomicMin(keys + rbase - ix, key);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    int any = 0;
+    for (int pix = tid; pix < rows * W; pix += MVR_BLOCK) {
+      const unsigned long long key = keys[pix];
+      const bool hit = key != MVR_KEY_EMPTY;
+      slots[(size_t)pix * K + k] = hit ? (int)(unsigned)(key & 0xffffffffull) : -1;
+      lo[pix] = hit ? key + 1ull : MVR_KEY_EMPTY;
+      any |= hit ? 1 : 0;
+    }
+    k_done = k + 1;
+    if (!__syncthreads_or(any)) break;  // no pixel of the strip found a k-th point: the remaining slots are empty
+  }
+  for (int pix = tid; pix < rows * W; pix += MVR_BLOCK)
+    for (int k = k_done; k < K; ++k) slots[(size_t)pix * K + k] = -1;
+  float *__restrict__ img = a.images + (size_t)n * 3 * HW + (size_t)r0 * W;
+  const float *__restrict__ cols = a.colors ? a.colors + 3 * (size_t)b * a.P : nullptr;
+  for (int pix = tid; pix < rows * W; pix += MVR_BLOCK) {
+    const int row = pix / W, col = pix - row * W;
+    const float px = px_tab[W - 1 - col], py = py_tab[jy_hi - row - jy_lo];
+    const int32_t *sl = slots + (size_t)pix * K;   // written by this same thread above
+    float cr = a.bg[0], cg = a.bg[1], cb = a.bg[2];
+    if (sl[0] >= 0) {
+      float cum = 0.f;
+      for (int k = 0; k < k_done; ++k) {
+        const int pi = sl[k];
+        if (pi < 0) break;
+        const float4 q = pv[pi];
+        const float dx = q.x - px, dy = q.y - py;
+        cum += 1.0f - (dx * dx + dy * dy) / a.r2w;
+      }
+      if (cum < 1e-4f) cum = 1e-4f;  // NormWeightedCompositor kEpsilon clamp
+      cr = cg = cb = 0.f;
+      for (int k = 0; k < k_done; ++k) {
+        const int pi = sl[k];
+        if (pi < 0) break;
+        const float4 q = pv[pi];
+        const float dx = q.x - px, dy = q.y - py;
+        const float w = 1.0f - (dx * dx + dy * dy) / a.r2w;
+        float f0 = a.obj[0], f1 = a.obj[1], f2 = a.obj[2];
+        if (cols) { f0 = cols[3 * (size_t)pi]; f1 = cols[3 * (size_t)pi + 1]; f2 = cols[3 * (size_t)pi + 2]; }
+        cr += (f0 * w) / cum; cg += (f1 * w) / cum; cb += (f2 * w) / cum;
+      }
+    }
+    img[pix] = cr; img[HW + pix] = cg; img[2 * HW + pix] = cb;
+  }
+}
+
 #define MVR_PACC 13  // gR[9], gT[3], g(1/dist)
 
 struct PointsBwdArgs {
   const float *points, *colors, *R, *T, *dist, *gimg;
   const int32_t *p2p;
   float *partials;  // (N, n_strips, 13)
-  int B, P, V, N, H, W, TH, n_strips, views_per_xcd;
+  int B, P, V, N, H, W, TH, n_strips, views_per_xcd, K;
   float r2w;
   float obj[3];
 };
@@ -1208,34 +1313,53 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_points_backward(PointsBwdArgs a) 
   const float sc = 1.0f / a.dist[n];
   const float *pts = a.points + 3 * (size_t)b * a.P;
   const float *cols = a.colors ? a.colors + 3 * (size_t)b * a.P : nullptr;
-  const int32_t *p2p = a.p2p + (size_t)n * HW + (size_t)r0 * W;
+  const int32_t *p2p = a.p2p + ((size_t)n * HW + (size_t)r0 * W) * a.K;
   const float *g = a.gimg + (size_t)n * 3 * HW + (size_t)r0 * W;
   float acc[MVR_PACC];
 #pragma unroll
   for (int k = 0; k < MVR_PACC; ++k) acc[k] = 0.f;
+  // PyTorch3D's norm_weighted_sum backward: d out_c / d w_k = (f_ck S - sum_j w_j f_cj) / S^2 with the CLAMPED
+  // S = max(sum_j w_j, 1e-4).  For K = 1 away from the clamp this is f w - w f = 0 exactly, so those pixels are skipped.
+  const int K = a.K;
   for (int pix = tid; pix < rows * W; pix += MVR_BLOCK) {
-    int pi = p2p[pix];
-    if (pi < 0) continue;
+    const int32_t *sl = p2p + (size_t)pix * K;
+    if (sl[0] < 0) continue;
     int row = pix / W, col = pix - row * W;
     float px = mvr::pix_to_ndc<float>(W - 1 - col, W), py = mvr::pix_to_ndc<float>(H - 1 - (r0 + row), H);
-    const float *pw = pts + 3 * (size_t)pi;
-    f3 q = point_view(Rm, Tv, sc, pw);
-    float dx = q.x - px, dy = q.y - py;
-    float dd = dx * dx + dy * dy;
-    float w = 1.0f - dd / a.r2w;
-    if (!(w < 1e-4f)) continue;  // out = (f w)/w: zero gradient unless the clamp is active
-    float f0 = a.obj[0], f1 = a.obj[1], f2 = a.obj[2];
-    if (cols) { f0 = cols[3 * (size_t)pi]; f1 = cols[3 * (size_t)pi + 1]; f2 = cols[3 * (size_t)pi + 2]; }
-    float gw = ((g[pix] * f0 + g[HW + pix] * f1) + g[2 * HW + pix] * f2) / 1e-4f;
-    float gdd = -gw / a.r2w;
-    float gx = 2.0f * dx * gdd, gy = 2.0f * dy * gdd;
-    // q = (sc * Xw) R + T
-    float xs = pw[0] * sc, ys = pw[1] * sc, zs = pw[2] * sc;
-    acc[0] += xs * gx; acc[1] += xs * gy;
-    acc[3] += ys * gx; acc[4] += ys * gy;
-    acc[6] += zs * gx; acc[7] += zs * gy;
-    acc[9] += gx; acc[10] += gy;
-    acc[12] += (pw[0] * Rm[0] + pw[1] * Rm[3] + pw[2] * Rm[6]) * gx + (pw[0] * Rm[1] + pw[1] * Rm[4] + pw[2] * Rm[7]) * gy;
+    float S = 0.f, A0 = 0.f, A1 = 0.f, A2 = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int pi = sl[k];
+      if (pi < 0) break;
+      f3 q = point_view(Rm, Tv, sc, pts + 3 * (size_t)pi);
+      float dx = q.x - px, dy = q.y - py;
+      float w = 1.0f - (dx * dx + dy * dy) / a.r2w;
+      float f0 = a.obj[0], f1 = a.obj[1], f2 = a.obj[2];
+      if (cols) { f0 = cols[3 * (size_t)pi]; f1 = cols[3 * (size_t)pi + 1]; f2 = cols[3 * (size_t)pi + 2]; }
+      S += w; A0 += w * f0; A1 += w * f1; A2 += w * f2;
+    }
+    if (K == 1 && !(S < 1e-4f)) continue;
+    if (S < 1e-4f) S = 1e-4f;
+    const float S2 = S * S;
+    const float g0 = g[pix], g1 = g[HW + pix], g2 = g[2 * HW + pix];
+    for (int k = 0; k < K; ++k) {
+      const int pi = sl[k];
+      if (pi < 0) break;
+      const float *pw = pts + 3 * (size_t)pi;
+      f3 q = point_view(Rm, Tv, sc, pw);
+      float dx = q.x - px, dy = q.y - py;
+      float f0 = a.obj[0], f1 = a.obj[1], f2 = a.obj[2];
+      if (cols) { f0 = cols[3 * (size_t)pi]; f1 = cols[3 * (size_t)pi + 1]; f2 = cols[3 * (size_t)pi + 2]; }
+      float gw = (((f0 * S - A0) / S2) * g0 + ((f1 * S - A1) / S2) * g1) + ((f2 * S - A2) / S2) * g2;
+      float gdd = -gw / a.r2w;
+      float gx = 2.0f * dx * gdd, gy = 2.0f * dy * gdd;
+      // q = (sc * Xw) R + T
+      float xs = pw[0] * sc, ys = pw[1] * sc, zs = pw[2] * sc;
+      acc[0] += xs * gx; acc[1] += xs * gy;
+      acc[3] += ys * gx; acc[4] += ys * gy;
+      acc[6] += zs * gx; acc[7] += zs * gy;
+      acc[9] += gx; acc[10] += gy;
+      acc[12] += (pw[0] * Rm[0] + pw[1] * Rm[3] + pw[2] * Rm[6]) * gx + (pw[0] * Rm[1] + pw[1] * Rm[4] + pw[2] * Rm[7]) * gy;
+    }
   }
 #pragma unroll
   for (int k = 0; k < MVR_PACC; ++k) {
@@ -1552,6 +1676,8 @@ int mvr_render_meshes_backward(const mvr_mesh_batch *meshes, const mvr_mesh_para
   return hip_check(hipGetLastError(), "k_mesh_backward_finalize");
 }
 
+static int points_k(const mvr_points_params *p) { return p->points_per_pixel > 0 ? p->points_per_pixel : 1; }
+
 static int points_strip_rows(const mvr_points_params *p) {
   if (p->strip_rows > 0) return p->strip_rows;
   int th = 2 * default_strip_rows(p->image_h, p->image_w);   // few LDS bytes besides the keys: taller strips pay (measured)
@@ -1562,6 +1688,7 @@ struct PointsWs {
   float4 *pv;            // N * pstride
   unsigned short *pbin;  // N * pstride
   float *partials;       // N * n_strips * 13
+  int32_t *slots;        // N * H * W * K, only for points_per_pixel > 1 (used when the caller passes no pix_to_point)
   int pstride;
   size_t bytes;
 };
@@ -1576,6 +1703,11 @@ static PointsWs points_ws_layout(const mvr_points_params *p, void *base) {
   w.pv = (float4 *)((char *)base + off); off += align_up(N * w.pstride * sizeof(float4), 256);
   w.pbin = (unsigned short *)((char *)base + off); off += align_up(N * w.pstride * sizeof(unsigned short), 256);
   w.partials = (float *)((char *)base + off); off += align_up(N * n_strips * MVR_PACC * sizeof(float), 256);
+  w.slots = nullptr;
+  if (points_k(p) > 1) {
+    w.slots = (int32_t *)((char *)base + off);
+    off += align_up(N * (size_t)p->image_h * p->image_w * points_k(p) * sizeof(int32_t), 256);
+  }
   w.bytes = off;
   return w;
 }
@@ -1590,6 +1722,8 @@ static int check_points_args(const mvr_points_params *p) {
   if (p->n_clouds <= 0 || p->n_points <= 0 || p->n_views <= 0 || p->image_h <= 0 || p->image_w <= 0)
     return set_err(MVR_ERR_INVALID_ARG, "bad points params");
   if (!(p->radius > 0.0)) return set_err(MVR_ERR_INVALID_ARG, "radius must be > 0");
+  if (p->points_per_pixel < 0 || p->points_per_pixel > 150 || p->reserved_ != 0)
+    return set_err(MVR_ERR_INVALID_ARG, "points_per_pixel must be in [0, 150] and reserved_ 0");
   if (p->image_h > 32767 || p->image_w > 32767) return set_err(MVR_ERR_UNSUPPORTED, "image side > 32767");
   if (p->image_h != p->image_w) return set_err(MVR_ERR_UNSUPPORTED, "non-square images are not supported");
   return MVR_OK;
@@ -1615,14 +1749,19 @@ int mvr_render_points_forward(const mvr_points_params *p, const float *points, c
   hipLaunchKernelGGL(k_points_project, dim3((a.P + MVR_BLOCK - 1) / MVR_BLOCK, a.N), dim3(MVR_BLOCK), 0, (hipStream_t)stream, a,
                      ws.pv, ws.pbin);
   HIP_TRY(hipGetLastError());
-  size_t lds = (size_t)a.TH * a.W * 8 + (size_t)(a.W + a.TH) * 4 + 16;
+  const int K = points_k(p);
+  size_t lds = (size_t)a.TH * a.W * (K > 1 ? 16 : 8) + (size_t)(a.W + a.TH) * 4 + 16;
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)k_points_raster_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const void *kern = K > 1 ? (const void *)k_points_raster_topk : (const void *)k_points_raster_shade;
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int grid = 8 * a.views_per_xcd * a.n_strips;
   {
     ProfScope prof(PROF_POINTS_FWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_points_raster_shade, dim3(grid), dim3(MVR_BLOCK), lds, (hipStream_t)stream, a);
+    if (K > 1)
+      hipLaunchKernelGGL(k_points_raster_topk, dim3(grid), dim3(MVR_BLOCK), lds, (hipStream_t)stream, a, K,
+                         pix_to_point ? pix_to_point : ws.slots);
+    else
+      hipLaunchKernelGGL(k_points_raster_shade, dim3(grid), dim3(MVR_BLOCK), lds, (hipStream_t)stream, a);
   }
   return hip_check(hipGetLastError(), "k_points_raster_shade");
 }
@@ -1642,6 +1781,7 @@ int mvr_render_points_backward(const mvr_points_params *p, const float *points, 
   a.B = p->n_clouds; a.P = p->n_points; a.V = p->n_views; a.N = a.B * a.V; a.H = p->image_h; a.W = p->image_w;
   a.TH = points_strip_rows(p); a.n_strips = (a.H + a.TH - 1) / a.TH; a.views_per_xcd = (a.N + 7) / 8;
   a.r2w = (float)(p->radius * p->radius);
+  a.K = points_k(p);
   for (int k = 0; k < 3; ++k) a.obj[k] = p->obj_color[k];
   hipStream_t st = (hipStream_t)stream;
   int grid = 8 * a.views_per_xcd * a.n_strips;

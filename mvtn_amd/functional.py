@@ -194,12 +194,12 @@ def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params):
 
 
 def render_points_fragments(points, colors, R, T, dist, params):
-    """(images, pix_to_point (N,H,W) int32) without autograd — for parity tests."""
+    """(images, pix_to_point int32: (N,H,W) for points_per_pixel == 1, else (N,H,W,K)) without autograd — for parity tests."""
     lib = _lib.load()
     R, T, dist = _f32c(R), _f32c(T), _f32c(dist)
     B, V, H, W = params.n_clouds, params.n_views, params.image_h, params.image_w
     images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=R.device)
-    p2p = torch.empty(B * V, H, W, dtype=torch.int32, device=R.device)
+    p2p = torch.empty(_p2p_shape(params), dtype=torch.int32, device=R.device)
     ws_bytes = lib.mvr_points_workspace_bytes(params)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=R.device)
     _lib.check(lib.mvr_render_points_forward(params, points.data_ptr(), _ptr(colors), R.data_ptr(), T.data_ptr(),
@@ -223,13 +223,19 @@ def vertex_normals(packed: PackedMeshes):
 # point-cloud path
 # ---------------------------------------------------------------------------------------------
 
-def points_params(n_clouds, n_points, n_views, image_size, radius, obj_color, bg_color, strip_rows=0):
+def points_params(n_clouds, n_points, n_views, image_size, radius, obj_color, bg_color, strip_rows=0, points_per_pixel=1):
     H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
-    p = _lib.PointsParams(n_clouds, n_points, n_views, H, W, strip_rows, radius)
+    p = _lib.PointsParams(n_clouds, n_points, n_views, H, W, strip_rows, int(points_per_pixel), 0, radius)
     for k in range(3):
         p.obj_color[k] = float(obj_color[k])
         p.bg_color[k] = float(bg_color[k])
     return p
+
+
+def _p2p_shape(params):
+    K = max(1, params.points_per_pixel)
+    shape = (params.n_clouds * params.n_views, params.image_h, params.image_w)
+    return shape if K == 1 else shape + (K,)
 
 
 class _RenderPoints(torch.autograd.Function):
@@ -243,7 +249,7 @@ class _RenderPoints(torch.autograd.Function):
         if R.shape[0] != N or dist.numel() != N:
             raise ValueError("R/T/dist must have B*V = %d rows" % N)
         images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=R.device)
-        p2p = torch.empty(N, H, W, dtype=torch.int32, device=R.device) if need_grad else None
+        p2p = torch.empty(_p2p_shape(params), dtype=torch.int32, device=R.device) if need_grad else None
         ws_bytes = lib.mvr_points_workspace_bytes(params)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=R.device)
         _lib.check(lib.mvr_render_points_forward(params, points.data_ptr(), _ptr(colors), R.data_ptr(), T.data_ptr(),

@@ -56,9 +56,10 @@ class MVRenderer(nn.Module):
         self._light_cache = {}  # (device, direction tuple) -> (1,3) tensor
         self.strip_rows = strip_rows
         # faces_per_pixel > 1 does not change a HardPhongShader image (hard_rgb_blend reads only
-        # the nearest face), so any value >= 1 renders identically; points_per_pixel > 1 would.
-        if int(points_per_pixel) != 1:
-            raise NotImplementedError("points_per_pixel != 1 is not implemented (reference default is 1, config.yaml:21)")
+        # the nearest face), so any value >= 1 renders identically; points_per_pixel = K > 1 does change
+        # the image (norm-weighted sum over the K nearest points) and runs the top-K rasteriser.
+        if not 1 <= int(points_per_pixel) <= 150:
+            raise ValueError("points_per_pixel must be in [1, 150]")
 
     # -- models/renderer.py:153-160 -----------------------------------------------------------
     def rendering_color(self, custom_color=(1.0, 0, 0)):
@@ -170,7 +171,8 @@ class MVRenderer(nn.Module):
         else:
             obj = [float(c) for c in color]
         params = F.points_params(B, P, self.nb_views, self.image_size, float(self.points_radius), obj,
-                                 [float(c) for c in background_color], strip_rows=self.strip_rows)
+                                 [float(c) for c in background_color], strip_rows=self.strip_rows,
+                                 points_per_pixel=int(self.points_per_pixel))
         if azim.numel() != B * self.nb_views:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (B, self.nb_views))
         flat_dist = flatten_views(dist)

@@ -186,3 +186,20 @@ def render_points(points, azim, elev, dist, image_size, radius=0.006, obj_color=
         ctypes.c_double(radius), ctypes.c_int(mode), _ptr(fixed),
         _ptr(images), _ptr(idx), _ptr(zbuf), _ptr(d2))
     return dict(images=images, idx=idx, zbuf=zbuf, dist2=d2, R=R, T=T)
+
+
+def norm_weighted_weight_grads(idx, dist2, feats, grad_images, radius):
+    """d loss / d w_k of NormWeightedCompositor as PyTorch3D's norm_weighted_sum backward computes it
+    (pytorch3d/csrc/compositing/norm_weighted_sum.cu|cpp, un-vendored: restated from the published algorithm):
+    (f_k S - sum_j w_j f_j) / S^2 * grad_out, summed over channels, with S = max(sum_j w_j, 1e-4) — i.e. the
+    unclamped quotient rule evaluated with the clamped S.  fp64.
+      idx, dist2: (N,H,W,K) fragments; feats: (N,H,W,K,3) colour of each slot; grad_images: (N,3,H,W)."""
+    idx = np.asarray(idx)
+    valid = idx >= 0
+    w = np.where(valid, 1.0 - np.asarray(dist2, np.float64) / (float(radius) * float(radius)), 0.0)
+    f = np.where(valid[..., None], np.asarray(feats, np.float64), 0.0)
+    S = np.maximum(w.sum(-1), 1e-4)                                   # (N,H,W)
+    A = (w[..., None] * f).sum(-2)                                     # (N,H,W,3)
+    G = np.moveaxis(np.asarray(grad_images, np.float64), 1, -1)        # (N,H,W,3)
+    gw = (((f * S[..., None, None] - A[..., None, :]) / (S * S)[..., None, None]) * G[..., None, :]).sum(-1)
+    return np.where(valid, gw, 0.0)

@@ -111,7 +111,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     # struct layouts agree with the header (sizes computed by hand from include/mvr.h)
     assert ctypes.sizeof(_lib.MeshBatch) == 6 * 4 + 5 * 8
     assert ctypes.sizeof(_lib.MeshParams) == 6 * 4 + 5 * 4 + 6 * 4
-    assert ctypes.sizeof(_lib.PointsParams) == 6 * 4 + 8 + 6 * 4
+    assert ctypes.sizeof(_lib.PointsParams) == 8 * 4 + 8 + 6 * 4
 
 
 def test_c_abi_argument_validation_without_gpu():
@@ -123,8 +123,16 @@ def test_c_abi_argument_validation_without_gpu():
     mb = _lib.MeshBatch(0, 0, 0, 0, 0, 0, None, None, None, None, None)
     mp = _lib.MeshParams(1, 8, 8, 0, 1, 0, 60.0, 0.5, 0.3, 0.2, 64.0)
     assert lib.mvr_render_meshes_forward(mb, mp, None, None, None, None, None, None, 0, None) == 1
-    pp = _lib.PointsParams(1, 10, 1, 8, 8, 0, -1.0)
+    pp = _lib.PointsParams(1, 10, 1, 8, 8, 0, 1, 0, -1.0)
     assert lib.mvr_render_points_forward(pp, None, None, None, None, None, None, None, None, 0, None) == 1
+    assert b"radius" in lib.mvr_last_error()
+    pp = _lib.PointsParams(1, 10, 1, 8, 8, 0, 151, 0, 0.01)
+    assert lib.mvr_render_points_forward(pp, None, None, None, None, None, None, None, None, 0, None) == 1
+    assert b"points_per_pixel" in lib.mvr_last_error()
+    from mvtn_amd import functional as F
+    pk = F.points_params(2, 100, 3, 32, 0.01, (1, 1, 1), (0, 0, 0), points_per_pixel=4)
+    p1 = F.points_params(2, 100, 3, 32, 0.01, (1, 1, 1), (0, 0, 0))
+    assert lib.mvr_points_workspace_bytes(pk) >= lib.mvr_points_workspace_bytes(p1) + 6 * 32 * 32 * 4 * 4
     assert lib.mvr_mesh_workspace_bytes(None, None) == 0
 
 
@@ -186,8 +194,9 @@ def test_mvrenderer_mode_switches():
     assert torch.equal(r.rendering_color(), torch_color("white"))
     assert MVRenderer(4, 32, light_direction="fixed").light_direction(None, None, None) == ((0, 1.0, 0),)
     assert MVRenderer(4, 32, object_color="custom").rendering_color((0.1, 0.2, 0.3)) == (0.1, 0.2, 0.3)
-    with pytest.raises(NotImplementedError):
-        MVRenderer(4, 32, points_per_pixel=5)
+    assert MVRenderer(4, 32, points_per_pixel=5).points_per_pixel == 5
+    with pytest.raises(ValueError):
+        MVRenderer(4, 32, points_per_pixel=0)
     with pytest.raises(ValueError):
         MVRenderer(4, 32, rotation_check="maybe")
 
