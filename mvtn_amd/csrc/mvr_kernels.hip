@@ -485,6 +485,18 @@ struct RasterArgs {
 __device__ __forceinline__ void decode_block(int bid, int n_strips, int views_per_xcd, int *n, int *strip) {
   // XCD-aware mapping: workgroups bid and bid+8 share an XCD (round-robin dispatch); give each
   // XCD a contiguous range of views so a mesh's faces / projected vertices stay in ONE L2.
+  // Within an XCD the order is heaviest-first: the centre strips of all its views, then outwards (objects are
+  // centred, so the outermost strips are the cheap / empty ones) — the tail of the launch is then filled with
+  // short workgroups instead of waiting for a late 100k-cycle one.
+  int xcd = bid & 7, j = bid >> 3;
+  const int rank = j / views_per_xcd, mid = n_strips >> 1;
+  *n = xcd * views_per_xcd + (j - rank * views_per_xcd);
+  *strip = (rank & 1) ? mid - ((rank + 1) >> 1) : mid + (rank >> 1);
+}
+
+// The point kernels are store-bound with near-uniform workgroups: plain view-major order (consecutive workgroups of
+// an XCD write consecutive strips of one image) measured 9 % faster than the heaviest-first order above.
+__device__ __forceinline__ void decode_block_view_major(int bid, int n_strips, int views_per_xcd, int *n, int *strip) {
   int xcd = bid & 7, j = bid >> 3;
   *n = xcd * views_per_xcd + j / n_strips;
   *strip = j % n_strips;
@@ -1099,7 +1111,7 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_points_raster_shade(PointsArgs a)
   float *px_tab = (float *)(keys + (size_t)TH * W);
   float *py_tab = px_tab + W;
   int n, strip;
-  decode_block(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
+  decode_block_view_major(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
   if (n >= a.N) return;
   const int tid = threadIdx.x;
   const int b = n / a.V;
@@ -1192,7 +1204,7 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_points_raster_topk(PointsArgs a, 
   float *px_tab = (float *)(lo + (size_t)TH * W);
   float *py_tab = px_tab + W;
   int n, strip;
-  decode_block(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
+  decode_block_view_major(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
   if (n >= a.N) return;
   const int tid = threadIdx.x;
   const int b = n / a.V;
@@ -1297,7 +1309,7 @@ struct PointsBwdArgs {
 __global__ void __launch_bounds__(MVR_BLOCK) k_points_backward(PointsBwdArgs a) {
   __shared__ float s_part[MVR_WAVES][MVR_PACC];
   int n, strip;
-  decode_block(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
+  decode_block_view_major(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
   if (n >= a.N) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = a.W, H = a.H;

@@ -53,3 +53,11 @@ print("    setup + prefix   : %5.1f %%" % (100 * d[:, 4].sum() / tot.sum()))
 print("    candidate loop   : %5.1f %%" % (100 * d[:, 5].sum() / tot.sum()))
 print("  shade + store      : %5.1f %%" % (100 * (d[:, 2] - d[:, 1]).sum() / tot.sum()))
 print("  per workgroup: listed faces mean %.1f max %d | candidates mean %.1f max %d" % (d[:, 6].mean(), d[:, 6].max(), d[:, 7].mean(), d[:, 7].max()))
+nl, nc = d[:, 6], d[:, 7]
+print("  listed-faces histogram (per workgroup):")
+for lo, hi in [(0, 1), (1, 65), (65, 129), (129, 257), (257, 321), (321, 385), (385, 513), (513, 769), (769, 100000)]:
+    m = (nl >= lo) & (nl < hi)
+    print("    [%4d, %5d): %5.1f %% of workgroups, %5.1f %% of cycles, candidates/face %.1f" %
+          (lo, hi, 100 * m.mean(), 100 * tot[m].sum() / tot.sum(), nc[m].sum() / max(1, nl[m].sum())))
+print("  cycles per workgroup by quartile of listed faces:", [int(np.mean(tot[(nl >= a) & (nl < b)])) if ((nl >= a) & (nl < b)).any() else 0
+                                                               for a, b in [(0, 1), (1, 129), (129, 257), (257, 513), (513, 10**6)]])
