@@ -412,11 +412,20 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_face_bins(MeshPtrs m, int V, int 
 // global gathers for the bins.
 #define MVR_PB_BLOCK 1024
 #define MVR_PB_LDS_VERTS 12288   // 12288 * 12 B = 144 KiB
+// Per-(view, row-bin) face lists (optional, `sl.off != nullptr`): off[n][g] .. off[n][g + 1] delimit, inside
+// list[n * cap ...], the faces whose bounding box can reach row-bin g — the rasteriser then reads its strip's faces
+// directly instead of scanning every face's 2-byte range.  The order inside a list depends on LDS atomics and may
+// vary between runs; the depth resolve is an order-independent min, so the images do not.  A view whose lists would
+// exceed `cap` entries gets off[n][n_bins] = -1 and the rasteriser falls back to the scan.
+struct StripLists { int *off; int *list; int cap, n_bins; };
+
 __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n, unsigned char *smem, int V, int H, int W, int G,
                                                        int stride, int cull_backfaces, const float *__restrict__ R,
                                                        const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
-                                                       unsigned short *__restrict__ bins) {
+                                                       unsigned short *__restrict__ bins, const StripLists sl = StripLists{nullptr, nullptr, 0, 0}) {
+  __shared__ int s_hist[256], s_cur[256];
   float *pl = (float *)smem;   // 3 * nv
+  if (sl.off && threadIdx.x < 256) s_hist[threadIdx.x] = 0;
   const int b = n / V, v = n - b * V;
   const int vo = m.vert_off[b], nv = m.vert_off[b + 1] - vo;
   const int fo = m.face_off[b], nf = m.face_off[b + 1] - fo;
@@ -441,7 +450,42 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
     const f3 v0 = {pl[3 * i0], pl[3 * i0 + 1], pl[3 * i0 + 2]};
     const f3 v1 = {pl[3 * i1], pl[3 * i1 + 1], pl[3 * i1 + 2]};
     const f3 v2 = {pl[3 * i2], pl[3 * i2 + 1], pl[3 * i2 + 2]};
-    bins[(size_t)n * stride + f] = face_bin_range(v0, v1, v2, H, W, G, cull_backfaces, px_lo, px_hi, py_lo, py_hi);
+    const unsigned short e = face_bin_range(v0, v1, v2, H, W, G, cull_backfaces, px_lo, px_hi, py_lo, py_hi);
+    bins[(size_t)n * stride + f] = e;
+    if (sl.off && e != MVR_BIN_NONE)
+      for (int g = e & 0xff; g <= (e >> 8); ++g) atomicAdd(&s_hist[g], 1);
+  }
+  if (!sl.off) return;
+  __syncthreads();
+  int *off = sl.off + (size_t)n * (sl.n_bins + 1);
+  if (threadIdx.x < 64) {   // exclusive scan of the <= 254 bin counts by one wave (4 per lane)
+    const int l = threadIdx.x;
+    int c[4], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = (4 * l + k < sl.n_bins) ? s_hist[4 * l + k] : 0; tot += c[k]; }
+    int incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (l >= o) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    const bool fits = total <= sl.cap;
+    int run = incl - tot;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (4 * l + k < sl.n_bins) { s_cur[4 * l + k] = fits ? run : -1; off[4 * l + k] = run; }
+      run += c[k];
+    }
+    if (l == 0) off[sl.n_bins] = fits ? total : -1;
+  }
+  __syncthreads();
+  if (s_cur[0] < 0) return;   // overflow: the rasteriser scans
+  int *lst = sl.list + (size_t)n * sl.cap;
+  for (int f = threadIdx.x; f < nf; f += MVR_PB_BLOCK) {
+    const unsigned e = bins[(size_t)n * stride + f];   // this thread's own store above
+    if (e == MVR_BIN_NONE) continue;
+    for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(&s_cur[g], 1)] = f;
   }
 }
 
@@ -459,15 +503,16 @@ __global__ void __launch_bounds__(MVR_PB_BLOCK) k_project_bins_view(MeshPtrs m, 
 __global__ void __launch_bounds__(1024) k_mesh_prepass(MeshPtrs m, int chunks, int V, int H, int W, int G, int stride,
                                                       int cull_backfaces, const float *__restrict__ R,
                                                       const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
-                                                      unsigned short *__restrict__ bins, float4 *__restrict__ vattr) {
+                                                      unsigned short *__restrict__ bins, float4 *__restrict__ vattr, StripLists sl) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int nb_attr = m.B * chunks;
   if ((int)blockIdx.x < nb_attr) vattr_mesh_lds_body(m, blockIdx.x / chunks, blockIdx.x % chunks, smem, vattr, nullptr);
-  else project_bins_view_body(m, (int)blockIdx.x - nb_attr, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins);
+  else project_bins_view_body(m, (int)blockIdx.x - nb_attr, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins, sl);
 }
 
 struct RasterArgs {
   MeshPtrs m;
+  StripLists sl;               // per-(view, strip) face lists of the pre-pass, or off == nullptr
   const unsigned short *bins;
   int bin_rows, bin_stride;
   const float4 *proj;
@@ -632,7 +677,20 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
   // pixel centre of NDC index i: -1 + (2 i + 1)/S, the division done as div_by with RN(1/S): bit-identical
   const float fW = (float)W, fH = (float)H, invW = 1.0f / fW, invH = 1.0f / fH;
 
+  // face list of this strip from the pre-pass (else: scan the view's row-bin ranges below)
+  const int *gl = nullptr;
+  int gl_n = 0;
+  if (a.sl.off) {
+    const int *off = a.sl.off + (size_t)n * (a.sl.n_bins + 1);
+    if (off[a.sl.n_bins] >= 0) {
+      const int o0 = off[strip];
+      gl = a.sl.list + (size_t)n * a.sl.cap + o0;
+      gl_n = (strip + 1 < a.sl.n_bins ? off[strip + 1] : off[a.sl.n_bins]) - o0;
+    }
+  }
+  const bool use_list = gl != nullptr;
   if (tid == 0) cnt[0] = 0;
+  if (use_list && gl_n > 0) for (int i = tid; i < rows * W; i += MVR_RB) keys[i] = MVR_KEY_EMPTY;
   __syncthreads();
 
   DIAG_STAMP(0);
@@ -642,6 +700,9 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
 #endif
   const int faces_per_pass = MVR_RB * 8 * MVR_V3_ROUNDS;
   for (int pbase = 0; pbase < nf; pbase += faces_per_pass) {
+    int total_hits = gl_n, my_pos = 0;
+    unsigned mask = 0;   // bit (8 r + k): face pbase + (r * BLOCK + tid) * 8 + k touches this strip
+    if (!use_list) {
     // ---- scan: the row-bin vectors of up to 8192 faces are requested up front (4 x 16 B per lane); hit masks
     //      stay in registers; one wave prefix sum + ONE LDS atomic per wave orders the hits ---------------------
     uint4 q[MVR_V3_ROUNDS];
@@ -652,7 +713,6 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       if (f0 < nf) q[r] = *reinterpret_cast<const uint4 *>(bins + f0);
     }
     if (pbase == 0) for (int i = tid; i < rows * W; i += MVR_RB) keys[i] = MVR_KEY_EMPTY;   // under the loads' latency
-    unsigned mask = 0;   // bit (8 r + k): face pbase + (r * BLOCK + tid) * 8 + k touches this strip
 #pragma unroll
     for (int r = 0; r < MVR_V3_ROUNDS; ++r) {
       const int f0 = pbase + (r * MVR_RB + tid) * 8;
@@ -674,11 +734,12 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     int wave_base = 0;
     if (lane == 63 && hincl) wave_base = atomicAdd(&cnt[0], hincl);
     wave_base = __shfl(wave_base, 63);
-    const int my_pos = wave_base + hincl - my_hits;   // rank of this lane's first hit in the pass
+    my_pos = wave_base + hincl - my_hits;   // rank of this lane's first hit in the pass
     __syncthreads();
-    const int total_hits = cnt[0];
+    total_hits = cnt[0];
+    }   // !use_list
     for (int win = 0; win < total_hits; win += MVR_LIST_CAP) {
-    {  // materialise hits [win, win + CAP) of the pass in the LDS list
+    if (!use_list) {  // materialise hits [win, win + CAP) of the pass in the LDS list
       int pos = my_pos - win;
       unsigned m = mask;
       while (m) {
@@ -687,8 +748,9 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
         if (pos >= 0 && pos < MVR_LIST_CAP) list[pos] = pbase + ((bit >> 3) * MVR_RB + tid) * 8 + (bit & 7);
         ++pos;
       }
+      __syncthreads();
     }
-    __syncthreads();
+    const int *lst = use_list ? gl + win : list;
     const int n_list = min(MVR_LIST_CAP, total_hits - win);
 #ifdef MVR_DIAG
     unsigned long long tc1 = clock64();
@@ -702,7 +764,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       // ---- setup: one lane per face of the batch ------------------------------------------------
       int my_cnt = 0;
       if (tid < nb) {
-        const int f = list[b0 + tid];
+        const int f = lst[b0 + tid];
         const mvr::FaceSetup<float> fs = load_face(proj, faces, f, cull);
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
         my_cnt = face_range(fs, W, H, jy_lo, jy_hi, &x0, &x1, &y0, &y1);
@@ -796,6 +858,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     tc0 = clock64();
 #endif
     }   // window
+    if (use_list) break;
     if (pbase + faces_per_pass < nf) {
       if (tid == 0) cnt[0] = 0;
       __syncthreads();
@@ -834,6 +897,13 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     sh.vcol = a.m.vert_colors ? a.m.vert_colors + 3 * (size_t)vo : nullptr;
   }
 
+  if (use_list && gl_n == 0) {   // nothing can touch this strip: background only (the keys were never initialised)
+    for (int pix = tid; pix < rows * W; pix += MVR_RB) {
+      img[pix] = a.bg[0]; img[HW + pix] = a.bg[1]; img[2 * HW + pix] = a.bg[2];
+      if (p2f) p2f[pix] = -1;
+    }
+    return;
+  }
   int *plist = (int *)coef;                       // the batch records are dead now: reuse their LDS
   const int plist_cap = (int)((sizeof(FaceCoef) + sizeof(int2)) * MVR_RBATCH / sizeof(int));
   const int n_pix = rows * W;
@@ -1430,6 +1500,9 @@ struct MeshWs {
   unsigned short *bins;  // N * bin_stride
   int bin_stride;
   float *partials;   // N * n_strips * 18
+  int *soff;         // N * (n_strips + 1) strip-list offsets (pre-pass)
+  int *slist;        // N * slist_cap face indices
+  int slist_cap;
   size_t bytes;
 };
 
@@ -1445,6 +1518,11 @@ static MeshWs mesh_ws_layout(const mvr_mesh_batch *m, const mvr_mesh_params *p, 
   w.bin_stride = (int)align_up((size_t)(m->max_faces > 0 ? m->max_faces : m->total_faces), 8);  // 8-byte vector reads need a multiple of 4
   w.bins = (unsigned short *)((char *)base + off); off += align_up(N * (size_t)w.bin_stride * sizeof(unsigned short), 256);
   w.partials = (float *)((char *)base + off); off += align_up(N * n_strips * MVR_NACC * sizeof(float), 256);
+  // strip lists: a face reaches 1.5 strips on average at the reference's sizes; 3 per face + slack for tiny meshes of
+  // screen-filling faces.  Views that need more fall back to the scan (decided on the device, per view).
+  w.slist_cap = (int)align_up((size_t)3 * (m->max_faces > 0 ? m->max_faces : m->total_faces) + (size_t)16 * n_strips, 64);
+  w.soff = (int *)((char *)base + off); off += align_up(N * (size_t)(n_strips + 1) * sizeof(int), 256);
+  w.slist = (int *)((char *)base + off); off += align_up(N * (size_t)w.slist_cap * sizeof(int), 256);
   w.bytes = off;
   return w;
 }
@@ -1594,6 +1672,7 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   const int max_faces = meshes->max_faces > 0 ? meshes->max_faces : meshes->total_faces;
   const int G = bin_rows_for(H, TH);
   const int cullf = (params->flags & MVR_CULL_BACKFACES) ? 1 : 0;
+  StripLists sl = {nullptr, nullptr, 0, 0};
   if (max_verts <= MVR_PB_LDS_VERTS) {
     // one pre-pass launch: per-mesh vertex attributes + per-view projection/binning side by side
     const int chunks = (max_verts + MVR_NRM_LDS_VERTS - 1) / MVR_NRM_LDS_VERTS;
@@ -1602,8 +1681,9 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
     const size_t lds_pp = lds_attr > lds_proj ? lds_attr : lds_proj;
     if (lds_pp > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp));
+    if (G == TH && n_strips <= 254) sl = StripLists{ws.soff, ws.slist, ws.slist_cap, n_strips};
     hipLaunchKernelGGL(k_mesh_prepass, dim3(meshes->n_meshes * chunks + N), dim3(1024), lds_pp, st, mp, chunks, V, H, W, G,
-                       ws.bin_stride, cullf, R, T, s, ws.proj, ws.bins, ws.vattr);
+                       ws.bin_stride, cullf, R, T, s, ws.proj, ws.bins, ws.vattr, sl);
     HIP_TRY(hipGetLastError());
   } else {
     rc = launch_vattr(meshes, ws, nullptr, st);
@@ -1625,7 +1705,7 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   }
 
   RasterArgs a;
-  a.bins = ws.bins; a.bin_rows = G; a.bin_stride = ws.bin_stride;
+  a.bins = ws.bins; a.bin_rows = G; a.bin_stride = ws.bin_stride; a.sl = sl;
   a.m = mp; a.proj = ws.proj; a.vattr = ws.vattr; a.R = R; a.T = T; a.light = light_dir;
   a.images = images; a.p2f = pix_to_face;
   a.V = V; a.N = N; a.H = H; a.W = W; a.TH = TH; a.n_strips = n_strips;

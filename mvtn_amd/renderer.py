@@ -84,19 +84,24 @@ class MVRenderer(nn.Module):
     def _cameras(self, azim, elev, dist):
         """R, T, status for the (B,V) angle tensors; "device" mode runs the remedy in the kernel."""
         if self.rotation_check == "device":
-            self.check_status(block=False)
-            self._calls += 1
-            seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
-            # 2 pinned int32 words the kernel writes directly (zero-copy).  They are pre-set to a sentinel, so
-            # "has this forward's status landed?" is a plain host read: no event, no copy, nothing on the stream.
-            host = self._status_pool.pop() if self._status_pool else torch.empty(2, dtype=torch.int32, pin_memory=True)
-            host.fill_(_STATUS_PENDING)
+            max_trials, seed, host = self._device_remedy_args()
             R, T, status = F.look_at_view_transform(flatten_views(dist), flatten_views(elev), flatten_views(azim),
-                                                    return_status=True, max_trials=EXAHSTION_LIMIT, seed=seed,
+                                                    return_status=True, max_trials=max_trials, seed=seed,
                                                     host_status=host)
-            self._pending.append(host)
             return R, T, status
         return F.look_at_view_transform(flatten_views(dist), flatten_views(elev), flatten_views(azim), return_status=True)
+
+    def _device_remedy_args(self):
+        """(max_trials, seed, pinned status words) of one forward in "device" mode."""
+        self.check_status(block=False)
+        self._calls += 1
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        # 2 pinned int32 words the kernel writes directly (zero-copy).  They are pre-set to a sentinel, so
+        # "has this forward's status landed?" is a plain host read: no event, no copy, nothing on the stream.
+        host = self._status_pool.pop() if self._status_pool else torch.empty(2, dtype=torch.int32, pin_memory=True)
+        host.fill_(_STATUS_PENDING)
+        self._pending.append(host)
+        return EXAHSTION_LIMIT, seed, host
 
     def check_status(self, block=True):
         """Raise the reference's sys.exit("Remedy did not work") if an earlier forward exhausted the
@@ -139,7 +144,9 @@ class MVRenderer(nn.Module):
         else:
             packed = PackedMeshes.from_meshes(meshes, device, vert_colors)
         N = packed.n_meshes * self.nb_views
-        if torch.is_tensor(lights):
+        if lights is None:            # "relative": camera position of every view, computed inside the fused node
+            light = None
+        elif torch.is_tensor(lights):
             light = lights
         else:
             key = (str(device), tuple(float(c) for row in lights for c in row))
@@ -148,15 +155,22 @@ class MVRenderer(nn.Module):
                 light = torch.tensor(lights, dtype=torch.float32).reshape(-1, 3).to(device)
                 if self.light_direction_type == "fixed":
                     self._light_cache[key] = light
-        params = F.mesh_params(self.nb_views, self.image_size, light.shape[0], obj, [float(c) for c in background_color],
+        n_light = N if light is None else light.shape[0]
+        params = F.mesh_params(self.nb_views, self.image_size, n_light, obj, [float(c) for c in background_color],
                                cull_backfaces=bool(self.cull_backfaces), perspective_correct=bool(self.perspective_correct),
                                strip_rows=self.strip_rows)
         if azim.numel() != N:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (packed.n_meshes, self.nb_views))
-        R, T, status = self._cameras(azim, elev, dist)
-        images = F.render_meshes(packed, R, T, light, params)
+        # look-at (+ remedy) -> light -> rasterise + shade as ONE autograd node
+        max_trials, seed, host = -1, 0, None
+        if self.rotation_check == "device":
+            max_trials, seed, host = self._device_remedy_args()
+        images, R, T, status = F.render_mesh_views(packed, flatten_views(azim), flatten_views(elev), flatten_views(dist),
+                                                   light, params, max_trials=max_trials, seed=seed, host_status=host)
         if self.rotation_check == "sync" and int(status[1].item()) != 0:
             R, T = self._remedy(azim, elev, dist)
+            if light is None:
+                light = F.camera_position_from_spherical_angles(flatten_views(dist), flatten_views(elev), flatten_views(azim))
             images = F.render_meshes(packed, R, T, light, params)
         return images, Cameras(R, T, "perspective")
 
@@ -194,7 +208,8 @@ class MVRenderer(nn.Module):
         background_color = torch_color(self.background_color, max_lightness=True)
         color = self.rendering_color(color)
         if not self.pc_rendering:
-            lights = self.light_direction(azim, elev, dist)
+            relative = not (self.light_direction_type == "fixed" or (self.light_direction_type == "random" and self.training))
+            lights = None if relative else self.light_direction(azim, elev, dist)
             return self.render_meshes(meshes=meshes, color=color, azim=azim, elev=elev, dist=dist, lights=lights,
                                       background_color=background_color)
         return self.render_points(points=points, color=color, azim=azim, elev=elev, dist=dist,
