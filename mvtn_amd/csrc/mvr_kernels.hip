@@ -22,6 +22,7 @@
 // mvr_math.h (shared with nothing outside this library; the CPU oracle restates it independently).
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -761,93 +762,136 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
 #ifdef MVR_DIAG
       unsigned long long ts0 = clock64();
 #endif
-      // ---- setup: one lane per face of the batch ------------------------------------------------
+      // ---- setup: one lane per face of the batch.  Faces without a candidate pixel in this strip are dropped: the
+      //      records are written at the face's RANK among the non-empty ones, so "next face" in the loop is ++e ----
       int my_cnt = 0;
+      FaceCoef q;
+      int2 rr = make_int2(0, 0);
       if (tid < nb) {
         const int f = lst[b0 + tid];
         const mvr::FaceSetup<float> fs = load_face(proj, faces, f, cull);
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
         my_cnt = face_range(fs, W, H, jy_lo, jy_hi, &x0, &x1, &y0, &y1);
-        FaceCoef q;
         q.a = make_float4(fs.v0.x, fs.v0.y, fs.v0.z, fs.v1.x);
         q.b = make_float4(fs.v1.y, fs.v1.z, fs.v2.x, fs.v2.y);
         q.c = make_float4(fs.v2.z, fs.area, fs.inv_area, __int_as_float(f));
-        coef[tid] = q;
-        rng[tid] = make_int2(x0 | (x1 << 16), y0 | (y1 << 16));
+        rr = make_int2(x0 | (x1 << 16), y0 | (y1 << 16));
       }
-      // workgroup exclusive prefix sum of the candidate counts
+      const bool has = my_cnt > 0;
+      const unsigned long long hb = __ballot(has);
+      // workgroup exclusive prefix sums of the candidate counts and of the non-empty flags
       int incl = my_cnt;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         int t = __shfl_up(incl, off);
         if (lane >= off) incl += t;
       }
-      if (lane == 63) cnt[1 + wave] = incl;
+      if (lane == 63) { cnt[1 + wave] = incl; cnt[1 + MVR_RW + wave] = __popcll(hb); }
       __syncthreads();
-      int wave_off = 0, total = 0;
+      int wave_off = 0, total = 0, rec_off = 0;
 #pragma unroll
       for (int w = 0; w < MVR_RW; ++w) {
-        int t = cnt[1 + w];
-        if (w < wave) wave_off += t;
+        const int t = cnt[1 + w], r = cnt[1 + MVR_RW + w];
+        if (w < wave) { wave_off += t; rec_off += r; }
         total += t;
       }
-      cum[tid] = wave_off + incl - my_cnt;
-      if (tid == 0) cum[MVR_RBATCH] = total;
-      __syncthreads();
 #ifdef MVR_DIAG
       unsigned long long ts1 = clock64();
       t_small += ts1 - ts0; n_large_tot += total;
 #endif
-      // ---- raster: balanced split of the batch's `total` (face, pixel) candidates over 256 lanes -------
+      // ---- raster: balanced split of the batch's `total` (face, pixel) candidates over the lanes ---------------
       const int quota = (total + MVR_RB - 1) / MVR_RB;
-      // face e owns the lanes whose run starts inside [cum[e], cum[e] + my_cnt): lanes ceil(cum[e]/quota) ... ;
-      // it writes its own index into start[] for them (no dependent LDS chain, unlike a binary search per lane)
-      if (my_cnt > 0) {
+      if (has) {
+        const int c = rec_off + __popcll(hb & ((1ull << lane) - 1ull));
         const int c0 = wave_off + incl - my_cnt;
+        coef[c] = q; rng[c] = rr; cum[c] = c0;
+        // the face owns the lanes whose run starts inside [c0, c0 + my_cnt): it writes its record index into start[]
+        // for them (no dependent LDS chain, unlike a binary search per lane)
         int l0 = (c0 + quota - 1) / quota, l1 = (c0 + my_cnt - 1) / quota;
         if (l1 > MVR_RB - 1) l1 = MVR_RB - 1;
-        for (int l = l0; l <= l1; ++l) start[l] = tid;
+        for (int l = l0; l <= l1; ++l) start[l] = c;
       }
       __syncthreads();
       const int p0 = tid * quota;
       int rem = min(quota, total - p0);
       if (rem > 0) {
-        // e = last entry with cum[e] <= p0  (upper_bound - 1); entries with zero candidates are skipped by it
-        int e = start[tid];   // the face whose candidates contain item p0 (written by that face's setup lane)
-        mvr::FaceSetup<float> fs;
-        int f, x0, x1, y0, y1, ix, jy, left;
+        int e = start[tid];   // the record whose candidates contain item p0
+        // per-face state.  Edge i of the exact test (mvr::face_test / edge_fn, same operations in the same order):
+        //   e0 = (px - X1) * (Y2 - Y1) - (py - Y1) * (X2 - X1),  e1 = (px - X2) * (Y0 - Y2) - (py - Y2) * (X0 - X2),
+        //   e2 = (px - X0) * (Y1 - Y0) - (py - Y0) * (X1 - X0); the second products only change with the row.
+        float X0, Y0, Z0, X1, Y1, Z1, X2, Y2, Z2, area, inv_area, A0, A1, A2, xmin, xmax, ymin, ymax;
+        unsigned sgn;
+        int f, x0, x1, ix, jy, left;
+        float py, R0, R1, R2;
+        bool rowok;
+        unsigned long long *kp;
+#define MVR_LOAD_FACE()                                                                                      \
+        {                                                                                                    \
+          const FaceCoef qq = coef[e];                                                                       \
+          X0 = qq.a.x; Y0 = qq.a.y; Z0 = qq.a.z; X1 = qq.a.w; Y1 = qq.b.x; Z1 = qq.b.y; X2 = qq.b.z; Y2 = qq.b.w; \
+          Z2 = qq.c.x; area = qq.c.y; inv_area = qq.c.z; f = __float_as_int(qq.c.w);                         \
+          A0 = Y2 - Y1; A1 = Y0 - Y2; A2 = Y1 - Y0;                                                          \
+          xmin = fminf(fminf(X0, X1), X2); xmax = fmaxf(fmaxf(X0, X1), X2);                                  \
+          ymin = fminf(fminf(Y0, Y1), Y2); ymax = fmaxf(fmaxf(Y0, Y1), Y2);                                  \
+          sgn = area > 0.0f ? 0u : 0x80000000u;                                                              \
+        }
+#define MVR_SET_ROW()                                                                                        \
+        {                                                                                                    \
+          py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);                                       \
+          R0 = (py - Y1) * (X2 - X1); R1 = (py - Y2) * (X0 - X2); R2 = (py - Y0) * (X1 - X0);                \
+          rowok = !(py > ymax) && !(py < ymin);                                                              \
+          kp = keys + (size_t)(jy_hi - jy) * W + (W - 1 - ix);                                               \
+        }
+        MVR_LOAD_FACE();
         {
-          unpack_face(coef[e], fs, f);
           const int2 r = rng[e];
-          x0 = r.x & 0xffff; x1 = r.x >> 16; y0 = r.y & 0xffff; y1 = r.y >> 16;
+          x0 = r.x & 0xffff; x1 = r.x >> 16;
+          const int y0 = r.y & 0xffff, y1 = r.y >> 16;
           const int bw = x1 - x0 + 1;
           const int o = p0 - cum[e];
           const int dy = o / bw;
           jy = y0 + dy; ix = x0 + (o - dy * bw);
           left = bw * (y1 - y0 + 1) - o;
         }
-        float py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);
+        MVR_SET_ROW();
         while (true) {
           const float px = -1.0f + mvr::div_by(2.0f * (float)ix + 1.0f, fW, invW);
-          float pz, w0, w1, w2;
-          if (mvr::face_test<float>(fs, px, py, persp, &pz, &w0, &w1, &w2)) {
-            unsigned long long key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f;
-            atomicMin(keys + (size_t)(jy_hi - jy) * W + (W - 1 - ix), key);
+          const float e0 = (px - X1) * A0 - R0, e1 = (px - X2) * A1 - R1, e2 = (px - X0) * A2 - R2;
+          // e_i / area > 0 requires e_i != 0 with the sign of area: flip the sign bit for back faces, then "> 0"
+          const float t0 = __uint_as_float(__float_as_uint(e0) ^ sgn), t1 = __uint_as_float(__float_as_uint(e1) ^ sgn),
+                      t2 = __uint_as_float(__float_as_uint(e2) ^ sgn);
+          const bool hit = (rowok & !(px > xmax) & !(px < xmin)) & ((t0 > 0.0f) & (t1 > 0.0f) & (t2 > 0.0f));
+          if (hit) {
+            float a0 = mvr::div_by(e0, area, inv_area), a1 = mvr::div_by(e1, area, inv_area), a2 = mvr::div_by(e2, area, inv_area);
+            if (persp) {
+              const float u0 = (a0 * Z1) * Z2, u1 = (Z0 * a1) * Z2, u2 = (Z0 * Z1) * a2;
+              const float den = fmaxf((u0 + u1) + u2, mvr::kEps);
+              const float yd = 1.0f / den;
+              a0 = mvr::div_by(u0, den, yd); a1 = mvr::div_by(u1, den, yd); a2 = mvr::div_by(u2, den, yd);
+            }
+            const float pz = (a0 * Z0 + a1 * Z1) + a2 * Z2;
+            if (!(pz < 0.0f) && a0 > 0.0f && a1 > 0.0f && a2 > 0.0f)
+              atomicMin(kp, ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f);
           }
           if (--rem == 0) break;
           if (--left == 0) {
-            do { ++e; } while (cum[e + 1] == cum[e]);   // next face with candidates (exists: rem > 0)
-            unpack_face(coef[e], fs, f);
+            ++e;
+            MVR_LOAD_FACE();
             const int2 r = rng[e];
-            x0 = r.x & 0xffff; x1 = r.x >> 16; y0 = r.y & 0xffff; y1 = r.y >> 16;
+            x0 = r.x & 0xffff; x1 = r.x >> 16;
+            const int y0 = r.y & 0xffff, y1 = r.y >> 16;
             left = (x1 - x0 + 1) * (y1 - y0 + 1);
             ix = x0; jy = y0;
-            py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);
+            MVR_SET_ROW();
           } else if (++ix > x1) {
             ix = x0; ++jy;
-            py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);
+            MVR_SET_ROW();
+          } else {
+            --kp;
           }
         }
+#undef MVR_LOAD_FACE
+#undef MVR_SET_ROW
       }
       __syncthreads();   // coef / rng / cum are rewritten by the next batch; keys are complete for this one
 #ifdef MVR_DIAG
@@ -1714,7 +1758,10 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   a.ambient = params->ambient; a.diffuse = params->diffuse; a.specular = params->specular; a.shininess = params->shininess;
   for (int k = 0; k < 3; ++k) { a.obj[k] = params->obj_color[k]; a.bg[k] = params->bg_color[k]; }
   size_t lds = (size_t)TH * W * 8 + (size_t)MVR_RBATCH * (sizeof(FaceCoef) + sizeof(int2)) + (size_t)(MVR_RBATCH + 1) * 4 +
-               (size_t)MVR_LIST_CAP * 4 + 16 * 4;
+               (size_t)MVR_LIST_CAP * 4 + 32 * 4;
+#ifdef MVR_DIAG
+  if (const char *pad = getenv("MVR_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
+#endif
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
   if (lds > 64 * 1024)
     HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_raster_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
