@@ -100,6 +100,11 @@ const char *mvr_last_error(void);
  * HIP events recorded on the stream it is launched on.  mvr_profile_end synchronises on those events and
  * returns, per kind {0: mesh raster+shade forward, 1: points raster+shade forward, 2: mesh backward},
  * the summed kernel time in ms and the number of launches (both host arrays of length 3). */
+/* Self-test of the rasteriser's correctly rounded reciprocal (hardware v_rcp_f32 + two Newton steps) against the
+ * IEEE division 1.0f / d for every float whose bit pattern lies in [lo_bits, hi_bits]; *n_bad (device) receives the
+ * number of mismatches, *first_bad (device) one offending bit pattern.  Used by the GPU parity tests only. */
+int mvr_selftest_rcp(uint32_t lo_bits, uint32_t hi_bits, uint32_t *n_bad, uint32_t *first_bad, mvr_stream_t stream);
+
 int mvr_profile_begin(void);
 int mvr_profile_end(double *total_ms, int32_t *launches);
 

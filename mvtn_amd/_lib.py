@@ -41,6 +41,7 @@ _MB, _MP, _PP = ctypes.POINTER(MeshBatch), ctypes.POINTER(MeshParams), ctypes.PO
 PROTOTYPES = {
     "mvr_version": (ctypes.c_int, []),
     "mvr_last_error": (ctypes.c_char_p, []),
+    "mvr_selftest_rcp": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "mvr_profile_begin": (ctypes.c_int, []),
     "mvr_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
     "mvr_look_at": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]),

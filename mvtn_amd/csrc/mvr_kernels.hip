@@ -36,7 +36,7 @@ typedef V3<float> f3;
 
 #define MVR_BLOCK 256
 #define MVR_WAVES (MVR_BLOCK / 64)
-#define MVR_LIST_CAP 1536       // LDS face list (4 B entries); a strip touched by more faces is processed in windows of this size
+#define MVR_LIST_CAP 256       // LDS face list (4 B entries); a strip touched by more faces is processed in windows of this size
 #define MVR_BATCH 256           // faces set up / rasterised per batch (one per lane in the setup phase)
 #define MVR_V3_ROUNDS 4          // scan: 8 faces per lane per round -> 256 * 8 * 4 = 8192 faces per pass
 #ifndef MVR_RB
@@ -44,7 +44,9 @@ typedef V3<float> f3;
 #endif
 #define MVR_RW (MVR_RB / 64)
 #define MVR_RBATCH MVR_RB        // faces set up per batch: one per lane
+#ifndef MVR_RB_WAVES_PER_SIMD
 #define MVR_RB_WAVES_PER_SIMD 4
+#endif
 #define MVR_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define MVR_NACC 18
 
@@ -639,6 +641,40 @@ __device__ __forceinline__ void unpack_face(const FaceCoef &q, mvr::FaceSetup<fl
   fs.drawable = true;
 }
 
+
+// ---- packed (2 x f32) arithmetic for a PAIR of horizontally adjacent pixels --------------------------------------
+// gfx950 issues v_pk_{add,mul,fma}_f32 at the rate of the scalar forms, and the rasteriser is bound by VALU issue
+// (SQ_ACTIVE_INST_VALU = 97 % of the kernel's cycles), so evaluating the exact test of two pixels with packed
+// instructions halves its cost.  Each lane-wise operation is the same IEEE operation as the scalar code's.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// mvr::div_by on two numerators (shared divisor b, y = RN(1 / b)) and on two (numerator, divisor) pairs
+__device__ __forceinline__ v2f div_by2(v2f a, float b, float y) { const v2f q = a * y; const v2f r = fma2((v2f)(-b), q, a); return fma2(r, (v2f)(y), q); }
+__device__ __forceinline__ v2f div_by2v(v2f a, v2f b, v2f y) { const v2f q = a * y; const v2f r = fma2(-b, q, a); return fma2(r, y, q); }
+// RN(1 / d) for normal d > 0 whose reciprocal is normal: hardware reciprocal (1 ulp) + two Newton steps with exact
+// residuals.  Equality with the IEEE division 1.0f / d over every mantissa and the exponents the rasteriser can
+// produce is checked exhaustively on the GPU by mvr_selftest_rcp (tests/test_gpu_parity.py).
+__device__ __forceinline__ v2f rcp_rn2(v2f d) {
+  v2f y = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  v2f e = fma2(-d, y, (v2f)(1.0f));
+  y = fma2(y, e, y);
+  e = fma2(-d, y, (v2f)(1.0f));
+  return fma2(y, e, y);
+}
+
+__global__ void k_selftest_rcp(unsigned lo_bits, unsigned hi_bits, unsigned *__restrict__ n_bad, unsigned *__restrict__ first_bad) {
+  const unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long b = (unsigned long long)lo_bits + 2 * i0; b <= hi_bits; b += 2 * stride) {
+    const unsigned b1 = (b + 1 <= hi_bits) ? (unsigned)(b + 1) : (unsigned)b;
+    const v2f d = {__uint_as_float((unsigned)b), __uint_as_float(b1)};
+    const v2f y = rcp_rn2(d);
+    const float r0 = 1.0f / d.x, r1 = 1.0f / d.y;
+    if (__float_as_uint(y.x) != __float_as_uint(r0)) { if (atomicAdd(n_bad, 1u) == 0) *first_bad = (unsigned)b; }
+    if (__float_as_uint(y.y) != __float_as_uint(r1)) { if (atomicAdd(n_bad, 1u) == 0) *first_bad = b1; }
+  }
+}
+
 // One workgroup per (view, strip of TH image rows).
 //   scan     : 2-byte row-bin ranges of the view's faces (k_face_bins) -> LDS list of faces touching the strip
 //   setup    : one lane per listed face: gather its 3 projected vertices, exact candidate range, coefficient
@@ -656,8 +692,10 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
   int2 *rng = (int2 *)(coef + MVR_RBATCH);                                      // MVR_RBATCH: x0|x1<<16 , y0|y1<<16
   int *cum = (int *)(rng + MVR_RBATCH);                                         // MVR_RBATCH + 1 exclusive prefix sums
   int *list = cum + (MVR_RBATCH + 1);                                           // MVR_LIST_CAP face indices
-  int *cnt = list + MVR_LIST_CAP;                                              // [0] list entries, [1..4] wave totals
-  __shared__ int start[MVR_RB];                                             // first face of every lane's run
+  int *cnt = list + MVR_LIST_CAP;                                              // [0] list entries, [1..] wave totals (32 ints)
+  float *px_tab = (float *)(cnt + 32);                                         // W + 1 pixel-centre x coordinates
+  float *py_tab = px_tab + (W + 1);                                            // TH pixel-centre y coordinates (NDC row jy_lo + i)
+  __shared__ unsigned short start[MVR_RB];                                  // first record of every lane's run
 
   int n, strip;
   decode_block(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
@@ -690,6 +728,8 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     }
   }
   const bool use_list = gl != nullptr;
+  for (int i = tid; i <= W; i += MVR_RB) px_tab[i] = -1.0f + mvr::div_by(2.0f * (float)i + 1.0f, fW, invW);
+  if (tid < rows) py_tab[tid] = -1.0f + mvr::div_by(2.0f * (float)(jy_lo + tid) + 1.0f, fH, invH);
   if (tid == 0) cnt[0] = 0;
   if (use_list && gl_n > 0) for (int i = tid; i < rows * W; i += MVR_RB) keys[i] = MVR_KEY_EMPTY;
   __syncthreads();
@@ -771,7 +811,16 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
         const int f = lst[b0 + tid];
         const mvr::FaceSetup<float> fs = load_face(proj, faces, f, cull);
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-        my_cnt = face_range(fs, W, H, jy_lo, jy_hi, &x0, &x1, &y0, &y1);
+        if (face_range(fs, W, H, jy_lo, jy_hi, &x0, &x1, &y0, &y1) > 0) {
+          // trim the conservative range to EXACTLY the pixel centres inside the face's bounding box (the rule of the
+          // reference's per-pixel bbox test, evaluated on the same float values), so the loop needs no bbox test
+          while (x0 <= x1 && px_tab[x0] < fs.xmin) ++x0;
+          while (x1 >= x0 && px_tab[x1] > fs.xmax) --x1;
+          while (y0 <= y1 && py_tab[y0 - jy_lo] < fs.ymin) ++y0;
+          while (y1 >= y0 && py_tab[y1 - jy_lo] > fs.ymax) --y1;
+          if (x0 <= x1 && y0 <= y1)
+            my_cnt = ((x1 - x0 + 2) >> 1) * (y1 - y0 + 1);   // work items = PAIRS of horizontally adjacent candidate pixels
+        }
         q.a = make_float4(fs.v0.x, fs.v0.y, fs.v0.z, fs.v1.x);
         q.b = make_float4(fs.v1.y, fs.v1.z, fs.v2.x, fs.v2.y);
         q.c = make_float4(fs.v2.z, fs.area, fs.inv_area, __int_as_float(f));
@@ -809,37 +858,41 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
         // for them (no dependent LDS chain, unlike a binary search per lane)
         int l0 = (c0 + quota - 1) / quota, l1 = (c0 + my_cnt - 1) / quota;
         if (l1 > MVR_RB - 1) l1 = MVR_RB - 1;
-        for (int l = l0; l <= l1; ++l) start[l] = c;
+        for (int l = l0; l <= l1; ++l) start[l] = (unsigned short)c;
       }
       __syncthreads();
       const int p0 = tid * quota;
+#ifdef MVR_ABL_NO_LOOP
+      int rem = 0;
+#else
       int rem = min(quota, total - p0);
+#endif
       if (rem > 0) {
         int e = start[tid];   // the record whose candidates contain item p0
         // per-face state.  Edge i of the exact test (mvr::face_test / edge_fn, same operations in the same order):
         //   e0 = (px - X1) * (Y2 - Y1) - (py - Y1) * (X2 - X1),  e1 = (px - X2) * (Y0 - Y2) - (py - Y2) * (X0 - X2),
         //   e2 = (px - X0) * (Y1 - Y0) - (py - Y0) * (X1 - X0); the second products only change with the row.
-        float X0, Y0, Z0, X1, Y1, Z1, X2, Y2, Z2, area, inv_area, A0, A1, A2, xmin, xmax, ymin, ymax;
-        unsigned sgn;
+        // For a back face (area < 0) the coefficients, the area and its reciprocal are all negated: every edge value
+        // and every quotient e_i / area is then bit-identical up to that common sign (IEEE negation is exact and
+        // commutes with rounding), and the barycentrics come out the same.
+        float X0, Y0, Z0, X1, Y1, Z1, X2, Y2, Z2, sarea, sinv, A0, A1, A2, B0, B1, B2;
         int f, x0, x1, ix, jy, left;
-        float py, R0, R1, R2;
-        bool rowok;
+        float R0, R1, R2;
         unsigned long long *kp;
 #define MVR_LOAD_FACE()                                                                                      \
         {                                                                                                    \
           const FaceCoef qq = coef[e];                                                                       \
           X0 = qq.a.x; Y0 = qq.a.y; Z0 = qq.a.z; X1 = qq.a.w; Y1 = qq.b.x; Z1 = qq.b.y; X2 = qq.b.z; Y2 = qq.b.w; \
-          Z2 = qq.c.x; area = qq.c.y; inv_area = qq.c.z; f = __float_as_int(qq.c.w);                         \
-          A0 = Y2 - Y1; A1 = Y0 - Y2; A2 = Y1 - Y0;                                                          \
-          xmin = fminf(fminf(X0, X1), X2); xmax = fmaxf(fmaxf(X0, X1), X2);                                  \
-          ymin = fminf(fminf(Y0, Y1), Y2); ymax = fmaxf(fmaxf(Y0, Y1), Y2);                                  \
-          sgn = area > 0.0f ? 0u : 0x80000000u;                                                              \
+          Z2 = qq.c.x; f = __float_as_int(qq.c.w);                                                           \
+          const float sg = qq.c.y > 0.0f ? 1.0f : -1.0f;                                                     \
+          sarea = sg * qq.c.y; sinv = sg * qq.c.z;                                                           \
+          A0 = sg * (Y2 - Y1); A1 = sg * (Y0 - Y2); A2 = sg * (Y1 - Y0);                                     \
+          B0 = sg * (X2 - X1); B1 = sg * (X0 - X2); B2 = sg * (X1 - X0);                                     \
         }
 #define MVR_SET_ROW()                                                                                        \
         {                                                                                                    \
-          py = -1.0f + mvr::div_by(2.0f * (float)jy + 1.0f, fH, invH);                                       \
-          R0 = (py - Y1) * (X2 - X1); R1 = (py - Y2) * (X0 - X2); R2 = (py - Y0) * (X1 - X0);                \
-          rowok = !(py > ymax) && !(py < ymin);                                                              \
+          const float py = py_tab[jy - jy_lo];                                                               \
+          R0 = (py - Y1) * B0; R1 = (py - Y2) * B1; R2 = (py - Y0) * B2;                                     \
           kp = keys + (size_t)(jy_hi - jy) * W + (W - 1 - ix);                                               \
         }
         MVR_LOAD_FACE();
@@ -847,32 +900,32 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
           const int2 r = rng[e];
           x0 = r.x & 0xffff; x1 = r.x >> 16;
           const int y0 = r.y & 0xffff, y1 = r.y >> 16;
-          const int bw = x1 - x0 + 1;
+          const int npx = (x1 - x0 + 2) >> 1;
           const int o = p0 - cum[e];
-          const int dy = o / bw;
-          jy = y0 + dy; ix = x0 + (o - dy * bw);
-          left = bw * (y1 - y0 + 1) - o;
+          const int dy = o / npx;
+          jy = y0 + dy; ix = x0 + 2 * (o - dy * npx);
+          left = npx * (y1 - y0 + 1) - o;
         }
         MVR_SET_ROW();
         while (true) {
-          const float px = -1.0f + mvr::div_by(2.0f * (float)ix + 1.0f, fW, invW);
-          const float e0 = (px - X1) * A0 - R0, e1 = (px - X2) * A1 - R1, e2 = (px - X0) * A2 - R2;
-          // e_i / area > 0 requires e_i != 0 with the sign of area: flip the sign bit for back faces, then "> 0"
-          const float t0 = __uint_as_float(__float_as_uint(e0) ^ sgn), t1 = __uint_as_float(__float_as_uint(e1) ^ sgn),
-                      t2 = __uint_as_float(__float_as_uint(e2) ^ sgn);
-          const bool hit = (rowok & !(px > xmax) & !(px < xmin)) & ((t0 > 0.0f) & (t1 > 0.0f) & (t2 > 0.0f));
-          if (hit) {
-            float a0 = mvr::div_by(e0, area, inv_area), a1 = mvr::div_by(e1, area, inv_area), a2 = mvr::div_by(e2, area, inv_area);
-            if (persp) {
-              const float u0 = (a0 * Z1) * Z2, u1 = (Z0 * a1) * Z2, u2 = (Z0 * Z1) * a2;
-              const float den = fmaxf((u0 + u1) + u2, mvr::kEps);
-              const float yd = 1.0f / den;
-              a0 = mvr::div_by(u0, den, yd); a1 = mvr::div_by(u1, den, yd); a2 = mvr::div_by(u2, den, yd);
-            }
-            const float pz = (a0 * Z0 + a1 * Z1) + a2 * Z2;
-            if (!(pz < 0.0f) && a0 > 0.0f && a1 > 0.0f && a2 > 0.0f)
-              atomicMin(kp, ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)f);
+          // two horizontally adjacent pixels (ix, ix + 1) per iteration, evaluated with packed f32 instructions;
+          // straight-line: the barycentrics of both are always computed, the final "> 0" tests decide (the sign
+          // pre-filter of mvr::face_test only skips work, it rejects nothing the final tests would accept)
+          const v2f px = {px_tab[ix], px_tab[ix + 1]};
+          const v2f t0 = (px - X1) * A0 - R0, t1 = (px - X2) * A1 - R1, t2 = (px - X0) * A2 - R2;
+          v2f a0 = div_by2(t0, sarea, sinv), a1 = div_by2(t1, sarea, sinv), a2 = div_by2(t2, sarea, sinv);
+          if (persp) {
+            const v2f u0 = (a0 * Z1) * Z2, u1 = (Z0 * a1) * Z2, u2 = (Z0 * Z1) * a2;
+            v2f den = (u0 + u1) + u2;
+            den.x = mvr::tmax(den.x, mvr::kEps); den.y = mvr::tmax(den.y, mvr::kEps);
+            const v2f yd = rcp_rn2(den);
+            a0 = div_by2v(u0, den, yd); a1 = div_by2v(u1, den, yd); a2 = div_by2v(u2, den, yd);
           }
+          const v2f pz = (a0 * Z0 + a1 * Z1) + a2 * Z2;
+          if ((a0.x > 0.0f) & (a1.x > 0.0f) & (a2.x > 0.0f) & !(pz.x < 0.0f))
+            atomicMin(kp, ((unsigned long long)__float_as_uint(pz.x + 0.0f) << 32) | (unsigned)f);
+          if ((ix < x1) & (a0.y > 0.0f) & (a1.y > 0.0f) & (a2.y > 0.0f) & !(pz.y < 0.0f))
+            atomicMin(kp - 1, ((unsigned long long)__float_as_uint(pz.y + 0.0f) << 32) | (unsigned)f);
           if (--rem == 0) break;
           if (--left == 0) {
             ++e;
@@ -880,14 +933,14 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
             const int2 r = rng[e];
             x0 = r.x & 0xffff; x1 = r.x >> 16;
             const int y0 = r.y & 0xffff, y1 = r.y >> 16;
-            left = (x1 - x0 + 1) * (y1 - y0 + 1);
+            left = ((x1 - x0 + 2) >> 1) * (y1 - y0 + 1);
             ix = x0; jy = y0;
             MVR_SET_ROW();
-          } else if (++ix > x1) {
+          } else if ((ix += 2) > x1) {
             ix = x0; ++jy;
             MVR_SET_ROW();
           } else {
-            --kp;
+            kp -= 2;
           }
         }
 #undef MVR_LOAD_FACE
@@ -1003,7 +1056,11 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       const int row = cur_pix / W, col = cur_pix - row * W;
       const float px = -1.0f + mvr::div_by(2.0f * (float)(W - 1 - col) + 1.0f, fW, invW);
       const float py = -1.0f + mvr::div_by(2.0f * (float)(jy_hi - row) + 1.0f, fH, invH);
+#ifdef MVR_ABL_NO_SHADE
+      const f3 rgb = {P0.x + N0.x + c0.x + px, P1.x + N1.y + c1.x + py, P2.x + N2.z + c2.x};
+#else
       const f3 rgb = shade_fast(P0, P1, P2, px, py, persp, N0, N1, N2, c0, c1, c2, sh, ci0, ci1, ci2);
+#endif
       img[cur_pix] = rgb.x; img[HW + cur_pix] = rgb.y; img[2 * HW + cur_pix] = rgb.z;
       if (p2f) p2f[cur_pix] = cur_face;
     }
@@ -1596,6 +1653,13 @@ int mvr_diag_set_buffer(void *dev_ptr) {
 
 int mvr_version(void) { return 100; }
 
+int mvr_selftest_rcp(uint32_t lo_bits, uint32_t hi_bits, uint32_t *n_bad, uint32_t *first_bad, mvr_stream_t stream) {
+  if (!n_bad || !first_bad || hi_bits < lo_bits) return set_err(MVR_ERR_INVALID_ARG, "mvr_selftest_rcp: bad argument");
+  HIP_TRY(hipMemsetAsync(n_bad, 0, sizeof(uint32_t), (hipStream_t)stream));
+  hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(256), 0, (hipStream_t)stream, lo_bits, hi_bits, n_bad, first_bad);
+  return hip_check(hipGetLastError(), "k_selftest_rcp");
+}
+
 int mvr_profile_begin(void) {
   for (int k = 0; k < PROF_KINDS; ++k) {
     for (auto &p : g_prof_ev[k]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -1758,7 +1822,7 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   a.ambient = params->ambient; a.diffuse = params->diffuse; a.specular = params->specular; a.shininess = params->shininess;
   for (int k = 0; k < 3; ++k) { a.obj[k] = params->obj_color[k]; a.bg[k] = params->bg_color[k]; }
   size_t lds = (size_t)TH * W * 8 + (size_t)MVR_RBATCH * (sizeof(FaceCoef) + sizeof(int2)) + (size_t)(MVR_RBATCH + 1) * 4 +
-               (size_t)MVR_LIST_CAP * 4 + 32 * 4;
+               (size_t)MVR_LIST_CAP * 4 + 32 * 4 + (size_t)(W + 1 + TH) * 4;
 #ifdef MVR_DIAG
   if (const char *pad = getenv("MVR_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
 #endif

@@ -343,9 +343,18 @@ template <typename T> MVR_HD bool face_test(const FaceSetup<T> &fs, T px, T py, 
 
 template <typename T> struct Phong { T ambient, diffuse, specular, shininess; };
 
+// a^shininess for a in [0, 1].  The reference's value (64, models/renderer.py uses the Materials default) is six
+// squarings.  Any other exponent: on the device exp2(s log2 a) with the hardware log/exp (relative error ~ s * 1e-7,
+// far inside the 1e-4 colour tolerance; a double-precision pow would drag ~200 f64 instructions and their registers
+// into the shading kernels for a path the reference never takes), on the host the libm pow.
 template <typename T> MVR_HD T pow_shininess(T a, T shininess) {
   if (shininess == (T)64) { T a2 = a * a, a4 = a2 * a2, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16; return a32 * a32; }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(a > (T)0)) return shininess == (T)0 ? (T)1 : (T)0;
+  return (T)__builtin_amdgcn_exp2f((float)shininess * __builtin_amdgcn_logf((float)a));
+#else
   return (T)pow((double)a, (double)shininess);
+#endif
 }
 
 // colour of one covered pixel.  X*, N*: world position / vertex normal of the face's

@@ -213,6 +213,21 @@ def test_mvrenderer_mesh_forward_backward(oracle, light, persp):
         assert rel < 2e-3, (name, got, ref)
 
 
+def test_refined_reciprocal_is_correctly_rounded_exhaustive():
+    """The rasteriser's perspective-correct barycentrics divide by den through y = RN(1/den) (Markstein); y comes
+    from v_rcp_f32 + two Newton steps.  Check y == 1.0f / den (IEEE) for EVERY float in [2^-30, 2^24): all 2^23
+    mantissas of 54 binades — den = max(., 1e-8) is >= 2^-27 and a sum of three z_i z_j-scaled barycentrics."""
+    from mvtn_amd import _lib
+    lib = _lib.load()
+    out = torch.zeros(2, dtype=torch.int32, device=_dev())
+    lo = np.array([2.0 ** -30], np.float32).view(np.uint32)[0]
+    hi = np.array([2.0 ** 24], np.float32).view(np.uint32)[0] - 1
+    _lib.check(lib.mvr_selftest_rcp(int(lo), int(hi), out[0:1].data_ptr(), out[1:2].data_ptr(), None), "mvr_selftest_rcp")
+    torch.cuda.synchronize()
+    n_bad, first = int(out[0]), int(out[1]) & 0xFFFFFFFF
+    assert n_bad == 0, "%d mismatches, e.g. bits 0x%08x" % (n_bad, first)
+
+
 def test_fused_mesh_views_node_equals_chained_nodes():
     """MVRenderer's single autograd node (look-at -> relative light -> render) gives the same images and gradients
     as the three chained nodes, including a loss term that differentiates through the returned cameras."""
