@@ -631,7 +631,8 @@ __device__ __forceinline__ mvr::FaceSetup<float> load_face(const float4 *__restr
 }
 
 // LDS record of one face of the current batch: everything the per-pixel test needs.
-struct FaceCoef { float4 a, b, c; };  // a = v0.xyz v1.x | b = v1.yz v2.xy | c = v2.z area inv_area face(bits)
+struct FaceCoef { float4 a, b, c; float2 d, e, g; };  // a = v0.xyz v1.x | b = v1.yz v2.xy | c = v2.z |area| 1/|area| face(bits)
+                                                      // d = A0 A1 | e = A2 B0 | g = B1 B2: edge coefficients times sign(area)
 
 __device__ __forceinline__ void unpack_face(const FaceCoef &q, mvr::FaceSetup<float> &fs, int &f) {
   fs.v0 = {q.a.x, q.a.y, q.a.z}; fs.v1 = {q.a.w, q.b.x, q.b.y}; fs.v2 = {q.b.z, q.b.w, q.c.x};
@@ -684,6 +685,7 @@ __global__ void k_selftest_rcp(unsigned lo_bits, unsigned hi_bits, unsigned *__r
 //              the prefix sums) -> no lane waits for another lane's big triangle; any face size is handled by
 //              the same loop.  Depth resolve: 64-bit LDS atomicMin on (float_bits(z) << 32 | face).
 //   shade    : every pixel of the strip: winner -> barycentrics -> Phong + hard blend -> planar store.
+template <bool PERSP>
 __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_shade(RasterArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int W = a.W, H = a.H, TH = a.TH;
@@ -711,7 +713,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
   const int rows = min(TH, H - r0);
   const int jy_hi = H - 1 - r0, jy_lo = jy_hi - (rows - 1);  // NDC row indices covered by the strip
   const unsigned g_lo = (unsigned)(r0 / a.bin_rows), g_hi = (unsigned)((r0 + rows - 1) / a.bin_rows);
-  const bool persp = (a.flags & MVR_PERSPECTIVE_CORRECT) != 0;
+  constexpr bool persp = PERSP;   // compile-time: the two variants share nothing in the hot loop
   const bool cull = (a.flags & MVR_CULL_BACKFACES) != 0;
   // pixel centre of NDC index i: -1 + (2 i + 1)/S, the division done as div_by with RN(1/S): bit-identical
   const float fW = (float)W, fH = (float)H, invW = 1.0f / fW, invH = 1.0f / fH;
@@ -823,7 +825,14 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
         }
         q.a = make_float4(fs.v0.x, fs.v0.y, fs.v0.z, fs.v1.x);
         q.b = make_float4(fs.v1.y, fs.v1.z, fs.v2.x, fs.v2.y);
-        q.c = make_float4(fs.v2.z, fs.area, fs.inv_area, __int_as_float(f));
+        // For a back face (area < 0) the edge coefficients, the area and its reciprocal are all negated: every edge
+        // value and every quotient e_i / area is then bit-identical up to that common sign (IEEE negation is exact
+        // and commutes with rounding), so the barycentrics come out the same and "inside" is "all three > 0".
+        const float sg = fs.area > 0.0f ? 1.0f : -1.0f;
+        q.c = make_float4(fs.v2.z, sg * fs.area, sg * fs.inv_area, __int_as_float(f));
+        q.d = make_float2(sg * (fs.v2.y - fs.v1.y), sg * (fs.v0.y - fs.v2.y));
+        q.e = make_float2(sg * (fs.v1.y - fs.v0.y), sg * (fs.v2.x - fs.v1.x));
+        q.g = make_float2(sg * (fs.v0.x - fs.v2.x), sg * (fs.v1.x - fs.v0.x));
         rr = make_int2(x0 | (x1 << 16), y0 | (y1 << 16));
       }
       const bool has = my_cnt > 0;
@@ -872,28 +881,24 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
         // per-face state.  Edge i of the exact test (mvr::face_test / edge_fn, same operations in the same order):
         //   e0 = (px - X1) * (Y2 - Y1) - (py - Y1) * (X2 - X1),  e1 = (px - X2) * (Y0 - Y2) - (py - Y2) * (X0 - X2),
         //   e2 = (px - X0) * (Y1 - Y0) - (py - Y0) * (X1 - X0); the second products only change with the row.
-        // For a back face (area < 0) the coefficients, the area and its reciprocal are all negated: every edge value
-        // and every quotient e_i / area is then bit-identical up to that common sign (IEEE negation is exact and
-        // commutes with rounding), and the barycentrics come out the same.
+        // The coefficients A_i = +-(Y_j - Y_k), B_i = +-(X_j - X_k), |area| and its reciprocal come signed from the setup.
         float X0, Y0, Z0, X1, Y1, Z1, X2, Y2, Z2, sarea, sinv, A0, A1, A2, B0, B1, B2;
         int f, x0, x1, ix, jy, left;
         float R0, R1, R2;
         unsigned long long *kp;
 #define MVR_LOAD_FACE()                                                                                      \
         {                                                                                                    \
-          const FaceCoef qq = coef[e];                                                                       \
-          X0 = qq.a.x; Y0 = qq.a.y; Z0 = qq.a.z; X1 = qq.a.w; Y1 = qq.b.x; Z1 = qq.b.y; X2 = qq.b.z; Y2 = qq.b.w; \
-          Z2 = qq.c.x; f = __float_as_int(qq.c.w);                                                           \
-          const float sg = qq.c.y > 0.0f ? 1.0f : -1.0f;                                                     \
-          sarea = sg * qq.c.y; sinv = sg * qq.c.z;                                                           \
-          A0 = sg * (Y2 - Y1); A1 = sg * (Y0 - Y2); A2 = sg * (Y1 - Y0);                                     \
-          B0 = sg * (X2 - X1); B1 = sg * (X0 - X2); B2 = sg * (X1 - X0);                                     \
+          const FaceCoef &qq = coef[e];                                                                      \
+          const float4 qa = qq.a, qb = qq.b, qc = qq.c;                                                      \
+          const float2 qd = qq.d, qe = qq.e, qg = qq.g;                                                      \
+          X0 = qa.x; Y0 = qa.y; Z0 = qa.z; X1 = qa.w; Y1 = qb.x; Z1 = qb.y; X2 = qb.z; Y2 = qb.w;            \
+          Z2 = qc.x; sarea = qc.y; sinv = qc.z; f = __float_as_int(qc.w);                                    \
+          A0 = qd.x; A1 = qd.y; A2 = qe.x; B0 = qe.y; B1 = qg.x; B2 = qg.y;                                  \
         }
 #define MVR_SET_ROW()                                                                                        \
         {                                                                                                    \
           const float py = py_tab[jy - jy_lo];                                                               \
           R0 = (py - Y1) * B0; R1 = (py - Y2) * B1; R2 = (py - Y0) * B2;                                     \
-          kp = keys + (size_t)(jy_hi - jy) * W + (W - 1 - ix);                                               \
         }
         MVR_LOAD_FACE();
         {
@@ -907,6 +912,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
           left = npx * (y1 - y0 + 1) - o;
         }
         MVR_SET_ROW();
+        kp = keys + (__mul24(jy_hi - jy, W) + (W - 1 - ix));
         while (true) {
           // two horizontally adjacent pixels (ix, ix + 1) per iteration, evaluated with packed f32 instructions;
           // straight-line: the barycentrics of both are always computed, the final "> 0" tests decide (the sign
@@ -936,10 +942,13 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
             left = ((x1 - x0 + 2) >> 1) * (y1 - y0 + 1);
             ix = x0; jy = y0;
             MVR_SET_ROW();
-          } else if ((ix += 2) > x1) {
+            kp = keys + (__mul24(jy_hi - jy, W) + (W - 1 - ix));
+          } else if (ix + 2 > x1) {
+            kp += (ix - x0) - W;   // next NDC row = previous image row, back to column x0
             ix = x0; ++jy;
             MVR_SET_ROW();
           } else {
+            ix += 2;
             kp -= 2;
           }
         }
@@ -1827,12 +1836,14 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   if (const char *pad = getenv("MVR_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
 #endif
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
-  if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_raster_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool persp = (params->flags & MVR_PERSPECTIVE_CORRECT) != 0;
+  const void *kern = persp ? (const void *)k_mesh_raster_shade<true> : (const void *)k_mesh_raster_shade<false>;
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int grid = 8 * a.views_per_xcd * n_strips;
   {
     ProfScope prof(PROF_MESH_FWD, st);
-    hipLaunchKernelGGL(k_mesh_raster_shade, dim3(grid), dim3(MVR_RB), lds, st, a);
+    if (persp) hipLaunchKernelGGL(k_mesh_raster_shade<true>, dim3(grid), dim3(MVR_RB), lds, st, a);
+    else hipLaunchKernelGGL(k_mesh_raster_shade<false>, dim3(grid), dim3(MVR_RB), lds, st, a);
   }
   return hip_check(hipGetLastError(), "k_mesh_raster_shade");
 }
