@@ -597,7 +597,13 @@ __device__ __forceinline__ f3 shade_fast(const f3 &P0, const f3 &P1, const f3 &P
             sh.cc.z - (w0 * X0.z + w1 * X1.z + w2 * X2.z)};
   }
   const f3 nn = {w0 * N0.x + w1 * N1.x + w2 * N2.x, w0 * N0.y + w1 * N1.y + w2 * N2.y, w0 * N0.z + w1 * N1.z + w2 * N2.z};
-  const f3 tex = {w0 * c0.x + w1 * c1.x + w2 * c2.x, w0 * c0.y + w1 * c1.y + w2 * c2.y, w0 * c0.z + w1 * c1.z + w2 * c2.z};
+  f3 tex;
+  if (sh.vcol) {
+    tex = {w0 * c0.x + w1 * c1.x + w2 * c2.x, w0 * c0.y + w1 * c1.y + w2 * c2.y, w0 * c0.z + w1 * c1.z + w2 * c2.z};
+  } else {   // one colour for the whole object: sum_i w_i c = (w0 + w1 + w2) c
+    const float ws = w0 + w1 + w2;
+    tex = {ws * sh.objc.x, ws * sh.objc.y, ws * sh.objc.z};
+  }
   const float eps2 = mvr::kNormalizeEps * mvr::kNormalizeEps;
   const float rn = __builtin_amdgcn_rsqf(fmaxf(nn.x * nn.x + nn.y * nn.y + nn.z * nn.z, eps2));  // v / max(|v|, eps)
   const f3 nh = {nn.x * rn, nn.y * rn, nn.z * rn};
@@ -628,6 +634,20 @@ __device__ __forceinline__ mvr::FaceSetup<float> load_face(const float4 *__restr
                                                           int f, bool cull) {
   int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
   return mvr::face_setup<float>(ld3(proj + i0), ld3(proj + i1), ld3(proj + i2), cull);
+}
+
+// The same for a face that is already known to be drawable (the pre-pass only bins / lists faces that pass the culls of
+// mvr::face_setup): bounding box, barycentric denominator and its reciprocal — identical values, no cull arithmetic.
+__device__ __forceinline__ mvr::FaceSetup<float> load_face_drawable(const float4 *__restrict__ proj, const int32_t *__restrict__ faces, int f) {
+  const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+  mvr::FaceSetup<float> fs;
+  fs.v0 = ld3(proj + i0); fs.v1 = ld3(proj + i1); fs.v2 = ld3(proj + i2);
+  fs.xmin = fminf(fminf(fs.v0.x, fs.v1.x), fs.v2.x); fs.xmax = fmaxf(fmaxf(fs.v0.x, fs.v1.x), fs.v2.x);
+  fs.ymin = fminf(fminf(fs.v0.y, fs.v1.y), fs.v2.y); fs.ymax = fmaxf(fmaxf(fs.v0.y, fs.v1.y), fs.v2.y);
+  fs.area = mvr::edge_fn(fs.v2.x, fs.v2.y, fs.v0.x, fs.v0.y, fs.v1.x, fs.v1.y) + mvr::kEps;
+  fs.inv_area = 1.0f / fs.area;
+  fs.drawable = true;
+  return fs;
 }
 
 // LDS record of one face of the current batch: everything the per-pixel test needs.
@@ -674,6 +694,17 @@ __global__ void k_selftest_rcp(unsigned lo_bits, unsigned hi_bits, unsigned *__r
     if (__float_as_uint(y.x) != __float_as_uint(r0)) { if (atomicAdd(n_bad, 1u) == 0) *first_bad = (unsigned)b; }
     if (__float_as_uint(y.y) != __float_as_uint(r1)) { if (atomicAdd(n_bad, 1u) == 0) *first_bad = b1; }
   }
+}
+
+
+// floor(x / d) for 0 <= x < 2^22 and d >= 1, given rd ~ 1 / d (relative error <= 2^-22): the float product is within
+// one of the quotient, one multiply-subtract settles it (a 32-bit integer division costs ~25 VALU instructions and
+// the rasteriser is bound by VALU issue).
+__device__ __forceinline__ int div_small(int x, int d, float rd) {
+  int q = (int)((float)x * rd);
+  const int r = x - q * d;
+  q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
 }
 
 // One workgroup per (view, strip of TH image rows).
@@ -811,7 +842,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       int2 rr = make_int2(0, 0);
       if (tid < nb) {
         const int f = lst[b0 + tid];
-        const mvr::FaceSetup<float> fs = load_face(proj, faces, f, cull);
+        const mvr::FaceSetup<float> fs = load_face_drawable(proj, faces, f);
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
         if (face_range(fs, W, H, jy_lo, jy_hi, &x0, &x1, &y0, &y1) > 0) {
           // trim the conservative range to EXACTLY the pixel centres inside the face's bounding box (the rule of the
@@ -859,13 +890,16 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
 #endif
       // ---- raster: balanced split of the batch's `total` (face, pixel) candidates over the lanes ---------------
       const int quota = (total + MVR_RB - 1) / MVR_RB;
+      const float rquota = 1.0f / (float)(quota > 0 ? quota : 1);
       if (has) {
         const int c = rec_off + __popcll(hb & ((1ull << lane) - 1ull));
         const int c0 = wave_off + incl - my_cnt;
         coef[c] = q; rng[c] = rr; cum[c] = c0;
         // the face owns the lanes whose run starts inside [c0, c0 + my_cnt): it writes its record index into start[]
         // for them (no dependent LDS chain, unlike a binary search per lane)
-        int l0 = (c0 + quota - 1) / quota, l1 = (c0 + my_cnt - 1) / quota;
+        int l0, l1;
+        if (total < (1 << 22)) { l0 = div_small(c0 + quota - 1, quota, rquota); l1 = div_small(c0 + my_cnt - 1, quota, rquota); }
+        else { l0 = (c0 + quota - 1) / quota; l1 = (c0 + my_cnt - 1) / quota; }
         if (l1 > MVR_RB - 1) l1 = MVR_RB - 1;
         for (int l = l0; l <= l1; ++l) start[l] = (unsigned short)c;
       }
@@ -907,7 +941,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
           const int y0 = r.y & 0xffff, y1 = r.y >> 16;
           const int npx = (x1 - x0 + 2) >> 1;
           const int o = p0 - cum[e];
-          const int dy = o / npx;
+          const int dy = div_small(o, npx, __builtin_amdgcn_rcpf((float)npx));   // o < 2^18: at most 8 rows of 2^14 pairs
           jy = y0 + dy; ix = x0 + 2 * (o - dy * npx);
           left = npx * (y1 - y0 + 1) - o;
         }
