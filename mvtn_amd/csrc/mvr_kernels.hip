@@ -420,15 +420,18 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_face_bins(MeshPtrs m, int V, int 
 // directly instead of scanning every face's 2-byte range.  The order inside a list depends on LDS atomics and may
 // vary between runs; the depth resolve is an order-independent min, so the images do not.  A view whose lists would
 // exceed `cap` entries gets off[n][n_bins] = -1 and the rasteriser falls back to the scan.
-struct StripLists { int *off; int *list; int cap, n_bins; };
+// Inside a list the faces NEARER than the object's centre (min z < z of the world origin in view space) come first and
+// front[n][g] counts them: the rasteriser draws them first and then rejects whole far faces against the depth they left
+// (hierarchical z; only an ordering heuristic — any order gives the same image).
+struct StripLists { int *off; int *list; int *front; int cap, n_bins; };
 
 __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n, unsigned char *smem, int V, int H, int W, int G,
                                                        int stride, int cull_backfaces, const float *__restrict__ R,
                                                        const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
-                                                       unsigned short *__restrict__ bins, const StripLists sl = StripLists{nullptr, nullptr, 0, 0}) {
-  __shared__ int s_hist[256], s_cur[256];
+                                                       unsigned short *__restrict__ bins, const StripLists sl = StripLists{nullptr, nullptr, nullptr, 0, 0}) {
+  __shared__ int s_hist[256], s_near[256], s_cur[256], s_cur_far[256];
   float *pl = (float *)smem;   // 3 * nv
-  if (sl.off && threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+  if (sl.off && threadIdx.x < 256) { s_hist[threadIdx.x] = 0; s_near[threadIdx.x] = 0; }
   const int b = n / V, v = n - b * V;
   const int vo = m.vert_off[b], nv = m.vert_off[b + 1] - vo;
   const int fo = m.face_off[b], nf = m.face_off[b + 1] - fo;
@@ -455,8 +458,10 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
     const f3 v2 = {pl[3 * i2], pl[3 * i2 + 1], pl[3 * i2 + 2]};
     const unsigned short e = face_bin_range(v0, v1, v2, H, W, G, cull_backfaces, px_lo, px_hi, py_lo, py_hi);
     bins[(size_t)n * stride + f] = e;
-    if (sl.off && e != MVR_BIN_NONE)
-      for (int g = e & 0xff; g <= (e >> 8); ++g) atomicAdd(&s_hist[g], 1);
+    if (sl.off && e != MVR_BIN_NONE) {
+      const bool near_face = fminf(fminf(v0.z, v1.z), v2.z) < Tv[2];
+      for (int g = e & 0xff; g <= (e >> 8); ++g) { atomicAdd(&s_hist[g], 1); if (near_face) atomicAdd(&s_near[g], 1); }
+    }
   }
   if (!sl.off) return;
   __syncthreads();
@@ -477,7 +482,11 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
     int run = incl - tot;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (4 * l + k < sl.n_bins) { s_cur[4 * l + k] = fits ? run : -1; off[4 * l + k] = run; }
+      if (4 * l + k < sl.n_bins) {
+        const int nn = s_near[4 * l + k];
+        s_cur[4 * l + k] = fits ? run : -1; s_cur_far[4 * l + k] = run + nn; off[4 * l + k] = run;
+        sl.front[(size_t)n * sl.n_bins + 4 * l + k] = nn;
+      }
       run += c[k];
     }
     if (l == 0) off[sl.n_bins] = fits ? total : -1;
@@ -488,7 +497,9 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
   for (int f = threadIdx.x; f < nf; f += MVR_PB_BLOCK) {
     const unsigned e = bins[(size_t)n * stride + f];   // this thread's own store above
     if (e == MVR_BIN_NONE) continue;
-    for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(&s_cur[g], 1)] = f;
+    const int32_t *__restrict__ fc = m.faces + 3 * (size_t)(fo + f);
+    const bool near_face = fminf(fminf(pl[3 * fc[0] + 2], pl[3 * fc[1] + 2]), pl[3 * fc[2] + 2]) < Tv[2];
+    for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(near_face ? &s_cur[g] : &s_cur_far[g], 1)] = f;
   }
 }
 
@@ -728,6 +739,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
   int *cnt = list + MVR_LIST_CAP;                                              // [0] list entries, [1..] wave totals (32 ints)
   float *px_tab = (float *)(cnt + 32);                                         // W + 1 pixel-centre x coordinates
   float *py_tab = px_tab + (W + 1);                                            // TH pixel-centre y coordinates (NDC row jy_lo + i)
+  unsigned *tz = (unsigned *)(py_tab + TH);                                    // (W + 7) / 8 tile depth bounds (hierarchical z)
   __shared__ unsigned short start[MVR_RB];                                  // first record of every lane's run
 
   int n, strip;
@@ -751,13 +763,14 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
 
   // face list of this strip from the pre-pass (else: scan the view's row-bin ranges below)
   const int *gl = nullptr;
-  int gl_n = 0;
+  int gl_n = 0, gl_near = 0;
   if (a.sl.off) {
     const int *off = a.sl.off + (size_t)n * (a.sl.n_bins + 1);
     if (off[a.sl.n_bins] >= 0) {
       const int o0 = off[strip];
       gl = a.sl.list + (size_t)n * a.sl.cap + o0;
       gl_n = (strip + 1 < a.sl.n_bins ? off[strip + 1] : off[a.sl.n_bins]) - o0;
+      gl_near = a.sl.front[(size_t)n * a.sl.n_bins + strip];
     }
   }
   const bool use_list = gl != nullptr;
@@ -812,7 +825,27 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     __syncthreads();
     total_hits = cnt[0];
     }   // !use_list
-    for (int win = 0; win < total_hits; win += MVR_LIST_CAP) {
+    // List mode draws the strip's faces in two segments: the near faces, then the far ones — and before the far ones it
+    // reduces the depth keys to one bound per 8-column tile, so that a far face whose nearest vertex lies behind
+    // everything already drawn over its bounding box is dropped in the setup (hierarchical z).  Sound for any order:
+    // such a face would lose the min at every one of its pixels.
+    for (int seg = 0; seg < (use_list ? 2 : 1); ++seg) {
+    const int seg_lo = (use_list && seg == 1) ? gl_near : 0;
+    const int seg_hi = use_list ? (seg == 0 ? gl_near : gl_n) : total_hits;
+    const bool hiz = use_list && seg == 1 && gl_near > 0 && seg_hi > seg_lo;
+    if (hiz) {
+      const int n_tiles = (W + 7) >> 3;
+      for (int i = tid; i < n_tiles; i += MVR_RB) tz[i] = 0u;
+      __syncthreads();
+      int col = tid % W;
+      const int dcol = MVR_RB % W;
+      for (int pix = tid; pix < rows * W; pix += MVR_RB) {
+        atomicMax(&tz[col >> 3], (unsigned)(keys[pix] >> 32));   // empty pixel: 0xFFFFFFFF, nothing is behind it
+        col += dcol; if (col >= W) col -= W;
+      }
+      __syncthreads();
+    }
+    for (int win = seg_lo; win < seg_hi; win += MVR_LIST_CAP) {
     if (!use_list) {  // materialise hits [win, win + CAP) of the pass in the LDS list
       int pos = my_pos - win;
       unsigned m = mask;
@@ -825,7 +858,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       __syncthreads();
     }
     const int *lst = use_list ? gl + win : list;
-    const int n_list = min(MVR_LIST_CAP, total_hits - win);
+    const int n_list = min(MVR_LIST_CAP, seg_hi - win);
 #ifdef MVR_DIAG
     unsigned long long tc1 = clock64();
     t_scan += tc1 - tc0; n_small_tot += n_list;
@@ -853,6 +886,17 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
           while (y1 >= y0 && py_tab[y1 - jy_lo] > fs.ymax) --y1;
           if (x0 <= x1 && y0 <= y1)
             my_cnt = ((x1 - x0 + 2) >> 1) * (y1 - y0 + 1);   // work items = PAIRS of horizontally adjacent candidate pixels
+          if (hiz && my_cnt > 0) {
+            // interpolated depth >= min vertex depth up to rounding (the barycentrics are positive and sum to 1 within
+            // a few ulp; without perspective correction the sum is 1 - kEps/area, hence the area guard there)
+            const float zmin = fminf(fminf(fs.v0.z, fs.v1.z), fs.v2.z);
+            const int t0 = (W - 1 - x1) >> 3, t1 = (W - 1 - x0) >> 3;
+            if (t1 - t0 <= 3 && zmin > 1e-3f && (PERSP || fabsf(fs.area) > 1e-3f)) {
+              unsigned zm = tz[t0];
+              for (int t = t0 + 1; t <= t1; ++t) zm = max(zm, tz[t]);
+              if (zmin * (1.0f - 1e-5f) > __uint_as_float(zm)) my_cnt = 0;   // 0xFFFFFFFF (an empty pixel) is a NaN: never true
+            }
+          }
         }
         q.a = make_float4(fs.v0.x, fs.v0.y, fs.v0.z, fs.v1.x);
         q.b = make_float4(fs.v1.y, fs.v1.z, fs.v2.x, fs.v2.y);
@@ -998,6 +1042,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     tc0 = clock64();
 #endif
     }   // window
+    }   // segment
     if (use_list) break;
     if (pbase + faces_per_pass < nf) {
       if (tid == 0) cnt[0] = 0;
@@ -1646,6 +1691,7 @@ struct MeshWs {
   float *partials;   // N * n_strips * 18
   int *soff;         // N * (n_strips + 1) strip-list offsets (pre-pass)
   int *slist;        // N * slist_cap face indices
+  int *sfront;       // N * n_strips: how many entries of each list are "near" faces (drawn first)
   int slist_cap;
   size_t bytes;
 };
@@ -1667,6 +1713,7 @@ static MeshWs mesh_ws_layout(const mvr_mesh_batch *m, const mvr_mesh_params *p, 
   w.slist_cap = (int)align_up((size_t)3 * (m->max_faces > 0 ? m->max_faces : m->total_faces) + (size_t)16 * n_strips, 64);
   w.soff = (int *)((char *)base + off); off += align_up(N * (size_t)(n_strips + 1) * sizeof(int), 256);
   w.slist = (int *)((char *)base + off); off += align_up(N * (size_t)w.slist_cap * sizeof(int), 256);
+  w.sfront = (int *)((char *)base + off); off += align_up(N * (size_t)n_strips * sizeof(int), 256);
   w.bytes = off;
   return w;
 }
@@ -1823,7 +1870,7 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   const int max_faces = meshes->max_faces > 0 ? meshes->max_faces : meshes->total_faces;
   const int G = bin_rows_for(H, TH);
   const int cullf = (params->flags & MVR_CULL_BACKFACES) ? 1 : 0;
-  StripLists sl = {nullptr, nullptr, 0, 0};
+  StripLists sl = {nullptr, nullptr, nullptr, 0, 0};
   if (max_verts <= MVR_PB_LDS_VERTS) {
     // one pre-pass launch: per-mesh vertex attributes + per-view projection/binning side by side
     const int chunks = (max_verts + MVR_NRM_LDS_VERTS - 1) / MVR_NRM_LDS_VERTS;
@@ -1832,7 +1879,7 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
     const size_t lds_pp = lds_attr > lds_proj ? lds_attr : lds_proj;
     if (lds_pp > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp));
-    if (G == TH && n_strips <= 254) sl = StripLists{ws.soff, ws.slist, ws.slist_cap, n_strips};
+    if (G == TH && n_strips <= 254) sl = StripLists{ws.soff, ws.slist, ws.sfront, ws.slist_cap, n_strips};
     hipLaunchKernelGGL(k_mesh_prepass, dim3(meshes->n_meshes * chunks + N), dim3(1024), lds_pp, st, mp, chunks, V, H, W, G,
                        ws.bin_stride, cullf, R, T, s, ws.proj, ws.bins, ws.vattr, sl);
     HIP_TRY(hipGetLastError());
@@ -1865,7 +1912,7 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   a.ambient = params->ambient; a.diffuse = params->diffuse; a.specular = params->specular; a.shininess = params->shininess;
   for (int k = 0; k < 3; ++k) { a.obj[k] = params->obj_color[k]; a.bg[k] = params->bg_color[k]; }
   size_t lds = (size_t)TH * W * 8 + (size_t)MVR_RBATCH * (sizeof(FaceCoef) + sizeof(int2)) + (size_t)(MVR_RBATCH + 1) * 4 +
-               (size_t)MVR_LIST_CAP * 4 + 32 * 4 + (size_t)(W + 1 + TH) * 4;
+               (size_t)MVR_LIST_CAP * 4 + 32 * 4 + (size_t)(W + 1 + TH) * 4 + (size_t)((W + 7) / 8) * 4;
 #ifdef MVR_DIAG
   if (const char *pad = getenv("MVR_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
 #endif
