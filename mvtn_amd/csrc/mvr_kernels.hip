@@ -424,11 +424,15 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_face_bins(MeshPtrs m, int V, int 
 // front[n][g] counts them: the rasteriser draws them first and then rejects whole far faces against the depth they left
 // (hierarchical z; only an ordering heuristic — any order gives the same image).
 struct StripLists { int *off; int *list; int *front; int cap, n_bins; };
+// Per-view shading constants written by the pre-pass (8 floats per view: normalised light direction, camera centre,
+// 1 / projection scale): uniform data the rasteriser would otherwise recompute in every lane of every workgroup.
+struct ViewConsts { float *out; const float *light; int n_light; };
 
 __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n, unsigned char *smem, int V, int H, int W, int G,
                                                        int stride, int cull_backfaces, const float *__restrict__ R,
                                                        const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
-                                                       unsigned short *__restrict__ bins, const StripLists sl = StripLists{nullptr, nullptr, nullptr, 0, 0}) {
+                                                       unsigned short *__restrict__ bins, const StripLists sl = StripLists{nullptr, nullptr, nullptr, 0, 0},
+                                                       const ViewConsts vc = ViewConsts{nullptr, nullptr, 0}) {
   __shared__ int s_hist[256], s_near[256], s_cur[256], s_cur_far[256];
   float *pl = (float *)smem;   // 3 * nv
   if (sl.off && threadIdx.x < 256) { s_hist[threadIdx.x] = 0; s_near[threadIdx.x] = 0; }
@@ -441,6 +445,13 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
 #pragma unroll
   for (int k = 0; k < 3; ++k) Tv[k] = T[3 * (size_t)n + k];
   float4 *__restrict__ proj = proj_all + (size_t)V * vo + (size_t)v * nv;
+  if (vc.out && threadIdx.x == 0) {
+    const float *lp = vc.light + 3 * (size_t)(vc.n_light == 1 ? 0 : n);
+    const f3 lh = mvr::normalize<float>({lp[0], lp[1], lp[2]}, mvr::kNormalizeEps);
+    const f3 cc = mvr::camera_center<float>(Rm, Tv);
+    float *o = vc.out + 8 * (size_t)n;
+    o[0] = lh.x; o[1] = lh.y; o[2] = lh.z; o[3] = cc.x; o[4] = cc.y; o[5] = cc.z; o[6] = 1.0f / s; o[7] = 0.f;
+  }
   for (int i = threadIdx.x; i < nv; i += MVR_PB_BLOCK) {
     const float *p = m.verts + 3 * (size_t)(vo + i);
     const f3 q = mvr::project_vertex<float>(Rm, Tv, s, {p[0], p[1], p[2]});
@@ -517,16 +528,18 @@ __global__ void __launch_bounds__(MVR_PB_BLOCK) k_project_bins_view(MeshPtrs m, 
 __global__ void __launch_bounds__(1024) k_mesh_prepass(MeshPtrs m, int chunks, int V, int H, int W, int G, int stride,
                                                       int cull_backfaces, const float *__restrict__ R,
                                                       const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
-                                                      unsigned short *__restrict__ bins, float4 *__restrict__ vattr, StripLists sl) {
+                                                      unsigned short *__restrict__ bins, float4 *__restrict__ vattr, StripLists sl,
+                                                      ViewConsts vc) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int nb_attr = m.B * chunks;
   if ((int)blockIdx.x < nb_attr) vattr_mesh_lds_body(m, blockIdx.x / chunks, blockIdx.x % chunks, smem, vattr, nullptr);
-  else project_bins_view_body(m, (int)blockIdx.x - nb_attr, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins, sl);
+  else project_bins_view_body(m, (int)blockIdx.x - nb_attr, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins, sl, vc);
 }
 
 struct RasterArgs {
   MeshPtrs m;
   StripLists sl;               // per-(view, strip) face lists of the pre-pass, or off == nullptr
+  const float *vconst;         // per-view shading constants of the pre-pass (8 floats), or nullptr
   const unsigned short *bins;
   int bin_rows, bin_stride;
   const float4 *proj;
@@ -774,10 +787,20 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     }
   }
   const bool use_list = gl != nullptr;
+  if (use_list && gl_n == 0) {   // nothing can touch this strip: background only
+    const size_t HW0 = (size_t)H * W;
+    float *__restrict__ img0 = a.images + (size_t)n * 3 * HW0 + (size_t)r0 * W;
+    int32_t *__restrict__ p2f0 = a.p2f ? a.p2f + (size_t)n * HW0 + (size_t)r0 * W : nullptr;
+    for (int pix = tid; pix < rows * W; pix += MVR_RB) {
+      img0[pix] = a.bg[0]; img0[HW0 + pix] = a.bg[1]; img0[2 * HW0 + pix] = a.bg[2];
+      if (p2f0) p2f0[pix] = -1;
+    }
+    return;
+  }
   for (int i = tid; i <= W; i += MVR_RB) px_tab[i] = -1.0f + mvr::div_by(2.0f * (float)i + 1.0f, fW, invW);
   if (tid < rows) py_tab[tid] = -1.0f + mvr::div_by(2.0f * (float)(jy_lo + tid) + 1.0f, fH, invH);
   if (tid == 0) cnt[0] = 0;
-  if (use_list && gl_n > 0) for (int i = tid; i < rows * W; i += MVR_RB) keys[i] = MVR_KEY_EMPTY;
+  if (use_list) for (int i = tid; i < rows * W; i += MVR_RB) keys[i] = MVR_KEY_EMPTY;
   __syncthreads();
 
   DIAG_STAMP(0);
@@ -1072,23 +1095,21 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     for (int k = 0; k < 3; ++k) Tv[k] = a.T[3 * (size_t)n + k];
 #pragma unroll
     for (int k = 0; k < 9; ++k) sh.Rm[k] = Rm[k];
-    sh.inv_s = 1.0f / a.s;
-    sh.cc = mvr::camera_center<float>(Rm, Tv);
-    const float *lp = a.light + 3 * (size_t)(a.n_light == 1 ? 0 : n);
-    sh.lh = mvr::normalize<float>({lp[0], lp[1], lp[2]}, mvr::kNormalizeEps);
+    if (a.vconst) {
+      const float *c = a.vconst + 8 * (size_t)n;
+      sh.lh = {c[0], c[1], c[2]}; sh.cc = {c[3], c[4], c[5]}; sh.inv_s = c[6];
+    } else {
+      sh.inv_s = 1.0f / a.s;
+      sh.cc = mvr::camera_center<float>(Rm, Tv);
+      const float *lp = a.light + 3 * (size_t)(a.n_light == 1 ? 0 : n);
+      sh.lh = mvr::normalize<float>({lp[0], lp[1], lp[2]}, mvr::kNormalizeEps);
+    }
     sh.objc = {a.obj[0], a.obj[1], a.obj[2]};
     sh.ambient = a.ambient; sh.diffuse = a.diffuse; sh.specular = a.specular; sh.shininess = a.shininess;
     sh.vat = a.vattr + 2 * (size_t)vo;
     sh.vcol = a.m.vert_colors ? a.m.vert_colors + 3 * (size_t)vo : nullptr;
   }
 
-  if (use_list && gl_n == 0) {   // nothing can touch this strip: background only (the keys were never initialised)
-    for (int pix = tid; pix < rows * W; pix += MVR_RB) {
-      img[pix] = a.bg[0]; img[HW + pix] = a.bg[1]; img[2 * HW + pix] = a.bg[2];
-      if (p2f) p2f[pix] = -1;
-    }
-    return;
-  }
   int *plist = (int *)coef;                       // the batch records are dead now: reuse their LDS
   const int plist_cap = (int)((sizeof(FaceCoef) + sizeof(int2)) * MVR_RBATCH / sizeof(int));
   const int n_pix = rows * W;
@@ -1692,6 +1713,7 @@ struct MeshWs {
   int *soff;         // N * (n_strips + 1) strip-list offsets (pre-pass)
   int *slist;        // N * slist_cap face indices
   int *sfront;       // N * n_strips: how many entries of each list are "near" faces (drawn first)
+  float *vconst;     // N * 8 per-view shading constants
   int slist_cap;
   size_t bytes;
 };
@@ -1714,6 +1736,7 @@ static MeshWs mesh_ws_layout(const mvr_mesh_batch *m, const mvr_mesh_params *p, 
   w.soff = (int *)((char *)base + off); off += align_up(N * (size_t)(n_strips + 1) * sizeof(int), 256);
   w.slist = (int *)((char *)base + off); off += align_up(N * (size_t)w.slist_cap * sizeof(int), 256);
   w.sfront = (int *)((char *)base + off); off += align_up(N * (size_t)n_strips * sizeof(int), 256);
+  w.vconst = (float *)((char *)base + off); off += align_up(N * 8 * sizeof(float), 256);
   w.bytes = off;
   return w;
 }
@@ -1871,6 +1894,7 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   const int G = bin_rows_for(H, TH);
   const int cullf = (params->flags & MVR_CULL_BACKFACES) ? 1 : 0;
   StripLists sl = {nullptr, nullptr, nullptr, 0, 0};
+  const float *vconst = nullptr;
   if (max_verts <= MVR_PB_LDS_VERTS) {
     // one pre-pass launch: per-mesh vertex attributes + per-view projection/binning side by side
     const int chunks = (max_verts + MVR_NRM_LDS_VERTS - 1) / MVR_NRM_LDS_VERTS;
@@ -1881,7 +1905,8 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
       HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp));
     if (G == TH && n_strips <= 254) sl = StripLists{ws.soff, ws.slist, ws.sfront, ws.slist_cap, n_strips};
     hipLaunchKernelGGL(k_mesh_prepass, dim3(meshes->n_meshes * chunks + N), dim3(1024), lds_pp, st, mp, chunks, V, H, W, G,
-                       ws.bin_stride, cullf, R, T, s, ws.proj, ws.bins, ws.vattr, sl);
+                       ws.bin_stride, cullf, R, T, s, ws.proj, ws.bins, ws.vattr, sl, ViewConsts{ws.vconst, light_dir, params->n_light});
+    vconst = ws.vconst;
     HIP_TRY(hipGetLastError());
   } else {
     rc = launch_vattr(meshes, ws, nullptr, st);
@@ -1903,7 +1928,7 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   }
 
   RasterArgs a;
-  a.bins = ws.bins; a.bin_rows = G; a.bin_stride = ws.bin_stride; a.sl = sl;
+  a.bins = ws.bins; a.bin_rows = G; a.bin_stride = ws.bin_stride; a.sl = sl; a.vconst = vconst;
   a.m = mp; a.proj = ws.proj; a.vattr = ws.vattr; a.R = R; a.T = T; a.light = light_dir;
   a.images = images; a.p2f = pix_to_face;
   a.V = V; a.N = N; a.H = H; a.W = W; a.TH = TH; a.n_strips = n_strips;
