@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_face_bins(MeshPtrs m, int V, int 
 // Inside a list the faces NEARER than the object's centre (min z < z of the world origin in view space) come first and
 // front[n][g] counts them: the rasteriser draws them first and then rejects whole far faces against the depth they left
 // (hierarchical z; only an ordering heuristic — any order gives the same image).
-struct StripLists { int *off; int *list; int *front; int cap, n_bins; };
+struct StripLists { int *off; int4 *list; int *front; int cap, n_bins; };   // list entries: (face, its 3 vertex indices)
 // Per-view shading constants written by the pre-pass (8 floats per view: normalised light direction, camera centre,
 // 1 / projection scale): uniform data the rasteriser would otherwise recompute in every lane of every workgroup.
 struct ViewConsts { float *out; const float *light; int n_light; };
@@ -504,13 +504,14 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
   }
   __syncthreads();
   if (s_cur[0] < 0) return;   // overflow: the rasteriser scans
-  int *lst = sl.list + (size_t)n * sl.cap;
+  int4 *lst = sl.list + (size_t)n * sl.cap;
   for (int f = threadIdx.x; f < nf; f += MVR_PB_BLOCK) {
     const unsigned e = bins[(size_t)n * stride + f];   // this thread's own store above
     if (e == MVR_BIN_NONE) continue;
     const int32_t *__restrict__ fc = m.faces + 3 * (size_t)(fo + f);
     const bool near_face = fminf(fminf(pl[3 * fc[0] + 2], pl[3 * fc[1] + 2]), pl[3 * fc[2] + 2]) < Tv[2];
-    for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(near_face ? &s_cur[g] : &s_cur_far[g], 1)] = f;
+    const int4 ent = make_int4(f, fc[0], fc[1], fc[2]);   // with the indices: the rasteriser's setup saves a dependent load
+    for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(near_face ? &s_cur[g] : &s_cur_far[g], 1)] = ent;
   }
 }
 
@@ -662,8 +663,7 @@ __device__ __forceinline__ mvr::FaceSetup<float> load_face(const float4 *__restr
 
 // The same for a face that is already known to be drawable (the pre-pass only bins / lists faces that pass the culls of
 // mvr::face_setup): bounding box, barycentric denominator and its reciprocal — identical values, no cull arithmetic.
-__device__ __forceinline__ mvr::FaceSetup<float> load_face_drawable(const float4 *__restrict__ proj, const int32_t *__restrict__ faces, int f) {
-  const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+__device__ __forceinline__ mvr::FaceSetup<float> load_face_drawable(const float4 *__restrict__ proj, int i0, int i1, int i2) {
   mvr::FaceSetup<float> fs;
   fs.v0 = ld3(proj + i0); fs.v1 = ld3(proj + i1); fs.v2 = ld3(proj + i2);
   fs.xmin = fminf(fminf(fs.v0.x, fs.v1.x), fs.v2.x); fs.xmax = fmaxf(fmaxf(fs.v0.x, fs.v1.x), fs.v2.x);
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
   const float fW = (float)W, fH = (float)H, invW = 1.0f / fW, invH = 1.0f / fH;
 
   // face list of this strip from the pre-pass (else: scan the view's row-bin ranges below)
-  const int *gl = nullptr;
+  const int4 *gl = nullptr;
   int gl_n = 0, gl_near = 0;
   if (a.sl.off) {
     const int *off = a.sl.off + (size_t)n * (a.sl.n_bins + 1);
@@ -796,6 +796,13 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       if (p2f0) p2f0[pix] = -1;
     }
     return;
+  }
+  // (face, indices) entry of this lane's face in the NEXT batch, requested one batch ahead (list mode): the setup then
+  // has one dependent gather (the projected vertices) instead of three
+  int4 ent_pf = make_int4(0, 0, 0, 0);
+  if (use_list) {
+    const int first = gl_near > 0 ? 0 : gl_near, first_hi = gl_near > 0 ? gl_near : gl_n;
+    if (first + tid < first_hi) ent_pf = gl[first + tid];
   }
   for (int i = tid; i <= W; i += MVR_RB) px_tab[i] = -1.0f + mvr::div_by(2.0f * (float)i + 1.0f, fW, invW);
   if (tid < rows) py_tab[tid] = -1.0f + mvr::div_by(2.0f * (float)(jy_lo + tid) + 1.0f, fH, invH);
@@ -880,7 +887,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       }
       __syncthreads();
     }
-    const int *lst = use_list ? gl + win : list;
+    const int *lst = list;
     const int n_list = min(MVR_LIST_CAP, seg_hi - win);
 #ifdef MVR_DIAG
     unsigned long long tc1 = clock64();
@@ -897,8 +904,10 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       FaceCoef q;
       int2 rr = make_int2(0, 0);
       if (tid < nb) {
-        const int f = lst[b0 + tid];
-        const mvr::FaceSetup<float> fs = load_face_drawable(proj, faces, f);
+        int4 ent = ent_pf;
+        if (!use_list) { const int ff = lst[b0 + tid]; ent = make_int4(ff, faces[3 * ff], faces[3 * ff + 1], faces[3 * ff + 2]); }
+        const int f = ent.x;
+        const mvr::FaceSetup<float> fs = load_face_drawable(proj, ent.y, ent.z, ent.w);
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
         if (face_range(fs, W, H, jy_lo, jy_hi, &x0, &x1, &y0, &y1) > 0) {
           // trim the conservative range to EXACTLY the pixel centres inside the face's bounding box (the rule of the
@@ -971,6 +980,11 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
         for (int l = l0; l <= l1; ++l) start[l] = (unsigned short)c;
       }
       __syncthreads();
+      if (use_list) {   // request the next batch's entries now; they land while this batch is rasterised
+        int nxt = win + MVR_LIST_CAP, nxt_hi = seg_hi;
+        if (nxt >= seg_hi) { if (seg == 0) { nxt = gl_near; nxt_hi = gl_n; } else { nxt = nxt_hi = 0; } }
+        if (nxt + tid < nxt_hi) ent_pf = gl[nxt + tid];
+      }
       const int p0 = tid * quota;
 #ifdef MVR_ABL_NO_LOOP
       int rem = 0;
@@ -1711,7 +1725,7 @@ struct MeshWs {
   int bin_stride;
   float *partials;   // N * n_strips * 18
   int *soff;         // N * (n_strips + 1) strip-list offsets (pre-pass)
-  int *slist;        // N * slist_cap face indices
+  int4 *slist;       // N * slist_cap (face, i0, i1, i2) entries
   int *sfront;       // N * n_strips: how many entries of each list are "near" faces (drawn first)
   float *vconst;     // N * 8 per-view shading constants
   int slist_cap;
@@ -1734,7 +1748,7 @@ static MeshWs mesh_ws_layout(const mvr_mesh_batch *m, const mvr_mesh_params *p, 
   // screen-filling faces.  Views that need more fall back to the scan (decided on the device, per view).
   w.slist_cap = (int)align_up((size_t)3 * (m->max_faces > 0 ? m->max_faces : m->total_faces) + (size_t)16 * n_strips, 64);
   w.soff = (int *)((char *)base + off); off += align_up(N * (size_t)(n_strips + 1) * sizeof(int), 256);
-  w.slist = (int *)((char *)base + off); off += align_up(N * (size_t)w.slist_cap * sizeof(int), 256);
+  w.slist = (int4 *)((char *)base + off); off += align_up(N * (size_t)w.slist_cap * sizeof(int4), 256);
   w.sfront = (int *)((char *)base + off); off += align_up(N * (size_t)n_strips * sizeof(int), 256);
   w.vconst = (float *)((char *)base + off); off += align_up(N * 8 * sizeof(float), 256);
   w.bytes = off;
