@@ -1214,7 +1214,13 @@ struct MeshBwdArgs {
   float obj[3];
 };
 
-__global__ void __launch_bounds__(MVR_BLOCK) k_mesh_backward(MeshBwdArgs a) {
+#ifndef MVR_BWD_STRIP_MULT
+#define MVR_BWD_STRIP_MULT 4
+#endif
+#ifndef MVR_BWD_WAVES_PER_SIMD
+#define MVR_BWD_WAVES_PER_SIMD 3   // 168 VGPRs without spills; 4 (128) spills 42 registers and doubles the time
+#endif
+__global__ void __launch_bounds__(MVR_BLOCK, MVR_BWD_WAVES_PER_SIMD) k_mesh_backward(MeshBwdArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   int *plist = (int *)smem;                               // rows * W covered-pixel indices
   __shared__ float s_part[MVR_WAVES][MVR_NACC];
@@ -1979,7 +1985,10 @@ int mvr_render_meshes_backward(const mvr_mesh_batch *meshes, const mvr_mesh_para
   if (workspace_bytes < ws.bytes) return set_err(MVR_ERR_WORKSPACE, "mvr_render_meshes_backward: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int V = params->n_views, N = meshes->n_meshes * V, H = params->image_h, W = params->image_w;
-  const int TH = params->strip_rows > 0 ? params->strip_rows : default_strip_rows(H, W);
+  // the backward keeps no depth keys in LDS: taller strips than the forward's amortise its compaction / reduction
+  // phases over more pixels (the partials buffer is sized for the forward's, larger, strip count)
+  int TH = params->strip_rows > 0 ? params->strip_rows : MVR_BWD_STRIP_MULT * default_strip_rows(H, W);
+  if (TH > H) TH = H;
   const int n_strips = (H + TH - 1) / TH;
   MeshPtrs mp = {meshes->verts, meshes->faces, meshes->vert_off, meshes->face_off, meshes->vert_colors, meshes->n_meshes};
   // vertex attributes: reuse the forward's when the caller hands back the same workspace, else recompute

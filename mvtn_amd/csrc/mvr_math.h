@@ -450,7 +450,7 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
       T a2_ = alpha * alpha, a4 = a2_ * a2_, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16;
       dpow = (T)64 * (((a32 * a16) * (a8 * a4)) * (a2_ * alpha));
     } else {
-      dpow = cam.ph.shininess * (T)pow((double)alpha, (double)cam.ph.shininess - 1.0);
+      dpow = cam.ph.shininess * pow_shininess(alpha, cam.ph.shininess - (T)1);
     }
     T g_dvr = cam.ph.specular * dpow * g_spec;
     V3<T> g_vh = {g_dvr * refl.x, g_dvr * refl.y, g_dvr * refl.z};
