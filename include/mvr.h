@@ -176,6 +176,32 @@ int mvr_render_meshes_backward(const mvr_mesh_batch *meshes, const mvr_mesh_para
                                float *grad_R, float *grad_T, float *grad_light,
                                void *workspace, size_t workspace_bytes, mvr_stream_t stream);
 
+/* ---- the whole mesh path of MVRenderer.forward in one call --------------------------------
+ * models/renderer.py:79-113: look_at_view_transform (+ check_and_correct_rotation_matrix on the device when
+ * max_trials >= 0, see mvr_look_at_checked) -> lights -> MeshRenderer(MeshRasterizer, HardPhongShader).  Same kernels as
+ * mvr_look_at_checked + mvr_camera_position + mvr_render_meshes_forward, fewer launches and one host call.
+ *   light_dir (params->n_light,3), or NULL for the reference's "relative" light_direction (models/renderer.py:168-169):
+ *   the camera position of every REQUESTED (azim, elev, dist) is written to light_used (N,3) and used as the light;
+ *   params->n_light must then be N.  azim_used / elev_used (N) receive the angles R, T were finally built from
+ *   (= the inputs unless the remedy re-drew them); view_valid / status as in mvr_look_at_checked (may be NULL). */
+int mvr_render_mesh_views_forward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params,
+                                  const float *azim, const float *elev, const float *dist,
+                                  int32_t max_trials, uint64_t seed, const float *light_dir,
+                                  float *R, float *T, float *azim_used, float *elev_used, float *light_used,
+                                  int32_t *view_valid, int32_t *status, float *images, int32_t *pix_to_face,
+                                  void *workspace, size_t workspace_bytes, mvr_stream_t stream);
+
+/* Its backward, (d azim, d elev, d dist) straight from grad_images: mvr_render_meshes_backward followed by
+ * mvr_look_at_backward at (azim_used, elev_used) and, if relative_light, mvr_camera_position_backward at
+ * (azim, elev), summed.  `light` is what the forward used (light_dir or light_used).  Pass the forward's workspace
+ * with MVR_WORKSPACE_FROM_FORWARD to reuse its vertex attributes. */
+int mvr_render_mesh_views_backward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params,
+                                   const float *azim, const float *elev, const float *dist,
+                                   const float *azim_used, const float *elev_used, const float *R, const float *T,
+                                   const float *light, int32_t relative_light, const int32_t *pix_to_face,
+                                   const float *grad_images, float *grad_azim, float *grad_elev, float *grad_dist,
+                                   void *workspace, size_t workspace_bytes, mvr_stream_t stream);
+
 /* ---- point-cloud path: models/renderer.py:116-151 ---------------------- */
 
 size_t mvr_points_workspace_bytes(const mvr_points_params *params);

@@ -41,6 +41,10 @@ _MB, _MP, _PP = ctypes.POINTER(MeshBatch), ctypes.POINTER(MeshParams), ctypes.PO
 PROTOTYPES = {
     "mvr_version": (ctypes.c_int, []),
     "mvr_last_error": (ctypes.c_char_p, []),
+    "mvr_render_mesh_views_forward": (ctypes.c_int, [_MB, _MP, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                                     ctypes.c_uint64] + [ctypes.c_void_p] * 11 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "mvr_render_mesh_views_backward": (ctypes.c_int, [_MB, _MP] + [ctypes.c_void_p] * 8 + [ctypes.c_int32] + [ctypes.c_void_p] * 6 +
+                                       [ctypes.c_size_t, ctypes.c_void_p]),
     "mvr_selftest_rcp": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "mvr_profile_begin": (ctypes.c_int, []),
     "mvr_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),

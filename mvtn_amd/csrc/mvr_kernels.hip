@@ -116,8 +116,13 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_look_at(const float *__restrict__
                                                        unsigned long long seed, float *__restrict__ R,
                                                        float *__restrict__ T, float *__restrict__ azim_used,
                                                        float *__restrict__ elev_used, int32_t *__restrict__ view_valid,
-                                                       int32_t *__restrict__ status) {
+                                                       int32_t *__restrict__ status, float *__restrict__ cam_pos = nullptr) {
   __shared__ int s_bad;
+  if (cam_pos)   // camera position of the requested angles: the reference's "relative" light (models/renderer.py:168-169)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const f3 c = mvr::camera_position<float>(azim[i], elev[i], dist[i]);
+      cam_pos[3 * i] = c.x; cam_pos[3 * i + 1] = c.y; cam_pos[3 * i + 2] = c.z;
+    }
   for (int trial = 0;; ++trial) {
     if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
@@ -1357,6 +1362,53 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_backward_finalize(const floa
   }
 }
 
+// The tail of a training step in ONE launch: sum the strips' partials of a view (as k_mesh_backward_finalize), then the
+// look-at backward at the angles the forward used and, for the relative light, the camera-position backward at the
+// requested angles (both in f64, rounded once, as k_look_at_bwd / k_camera_position_bwd), added together.
+__global__ void __launch_bounds__(MVR_BLOCK) k_mesh_views_backward_finalize(const float *__restrict__ partials, int N, int n_strips,
+                                                                            const float *__restrict__ R, const float *__restrict__ T,
+                                                                            const float *__restrict__ azim, const float *__restrict__ elev,
+                                                                            const float *__restrict__ dist,
+                                                                            const float *__restrict__ azim_used,
+                                                                            const float *__restrict__ elev_used, int relative_light,
+                                                                            float *__restrict__ g_azim, float *__restrict__ g_elev,
+                                                                            float *__restrict__ g_dist) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (MVR_BLOCK / 64) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[MVR_NACC];
+#pragma unroll
+  for (int k = 0; k < MVR_NACC; ++k) acc[k] = 0.f;
+  for (int s = lane; s < n_strips; s += 64) {
+    const float *p = partials + ((size_t)n * n_strips + s) * MVR_NACC;
+#pragma unroll
+    for (int k = 0; k < MVR_NACC; ++k) acc[k] += p[k];
+  }
+#pragma unroll
+  for (int k = 0; k < MVR_NACC; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
+  }
+  if (lane == 0) {
+    float Rm[9], Tv[3];
+    for (int k = 0; k < 9; ++k) Rm[k] = R[9 * (size_t)n + k];
+    for (int k = 0; k < 3; ++k) Tv[k] = T[3 * (size_t)n + k];
+    mvr::fold_camera_center<float>(Rm, Tv, acc + 12, acc, acc + 9);
+    double gr[9], gt[3], ga, ge, gd;
+    for (int k = 0; k < 9; ++k) gr[k] = (double)acc[k];
+    for (int k = 0; k < 3; ++k) gt[k] = (double)acc[9 + k];
+    mvr::look_at_bwd<double>((double)azim_used[n], (double)elev_used[n], (double)dist[n], gr, gt, &ga, &ge, &gd);
+    float fa = (float)ga, fe = (float)ge, fd = (float)gd;
+    if (relative_light) {
+      const V3<double> gl = {(double)acc[15], (double)acc[16], (double)acc[17]};
+      double la, le, ld;
+      mvr::camera_position_bwd<double>((double)azim[n], (double)elev[n], (double)dist[n], gl, &la, &le, &ld);
+      fa += (float)la; fe += (float)le; fd += (float)ld;   // two float gradients added, like autograd's accumulation
+    }
+    g_azim[n] = fa; g_elev[n] = fe; g_dist[n] = fd;
+  }
+}
+
 // ======================================================================================
 // point clouds: one workgroup per (view, strip)
 // ======================================================================================
@@ -1974,12 +2026,58 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   return hip_check(hipGetLastError(), "k_mesh_raster_shade");
 }
 
+struct ViewsBwd { const float *azim, *elev, *dist, *azim_used, *elev_used; int relative; float *g_azim, *g_elev, *g_dist; };
+
+static int mesh_backward_impl(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const float *R, const float *T,
+                              const float *light_dir, const int32_t *pix_to_face, const float *grad_images, float *grad_R,
+                              float *grad_T, float *grad_light, void *workspace, size_t workspace_bytes, mvr_stream_t stream,
+                              const ViewsBwd *vb);
+
+int mvr_render_mesh_views_forward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const float *azim, const float *elev,
+                                  const float *dist, int32_t max_trials, uint64_t seed, const float *light_dir, float *R, float *T,
+                                  float *azim_used, float *elev_used, float *light_used, int32_t *view_valid, int32_t *status,
+                                  float *images, int32_t *pix_to_face, void *workspace, size_t workspace_bytes,
+                                  mvr_stream_t stream) {
+  int rc = check_mesh_args(meshes, params);
+  if (rc != MVR_OK) return rc;
+  if (!azim || !elev || !dist || !R || !T || !images || !workspace || (!light_dir && !light_used))
+    return set_err(MVR_ERR_INVALID_ARG, "mvr_render_mesh_views_forward: null pointer");
+  const int N = meshes->n_meshes * params->n_views;
+  if (!light_dir && params->n_light != N) return set_err(MVR_ERR_INVALID_ARG, "relative light needs n_light == B*V");
+  hipLaunchKernelGGL(k_look_at, dim3(1), dim3(MVR_BLOCK), 0, (hipStream_t)stream, azim, elev, dist, N, (int)max_trials,
+                     (unsigned long long)seed, R, T, azim_used, elev_used, view_valid, status, light_dir ? nullptr : light_used);
+  HIP_TRY(hipGetLastError());
+  return mvr_render_meshes_forward(meshes, params, R, T, light_dir ? light_dir : light_used, images, pix_to_face, workspace,
+                                   workspace_bytes, stream);
+}
+
 int mvr_render_meshes_backward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const float *R, const float *T,
                                const float *light_dir, const int32_t *pix_to_face, const float *grad_images, float *grad_R,
                                float *grad_T, float *grad_light, void *workspace, size_t workspace_bytes, mvr_stream_t stream) {
+  if (!grad_R || !grad_T) return set_err(MVR_ERR_INVALID_ARG, "mvr_render_meshes_backward: null pointer");
+  return mesh_backward_impl(meshes, params, R, T, light_dir, pix_to_face, grad_images, grad_R, grad_T, grad_light, workspace,
+                            workspace_bytes, stream, nullptr);
+}
+
+int mvr_render_mesh_views_backward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const float *azim, const float *elev,
+                                   const float *dist, const float *azim_used, const float *elev_used, const float *R,
+                                   const float *T, const float *light, int32_t relative_light, const int32_t *pix_to_face,
+                                   const float *grad_images, float *grad_azim, float *grad_elev, float *grad_dist,
+                                   void *workspace, size_t workspace_bytes, mvr_stream_t stream) {
+  if (!azim || !elev || !dist || !azim_used || !elev_used || !grad_azim || !grad_elev || !grad_dist)
+    return set_err(MVR_ERR_INVALID_ARG, "mvr_render_mesh_views_backward: null pointer");
+  const ViewsBwd vb = {azim, elev, dist, azim_used, elev_used, relative_light ? 1 : 0, grad_azim, grad_elev, grad_dist};
+  return mesh_backward_impl(meshes, params, R, T, light, pix_to_face, grad_images, nullptr, nullptr, nullptr, workspace,
+                            workspace_bytes, stream, &vb);
+}
+
+static int mesh_backward_impl(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const float *R, const float *T,
+                              const float *light_dir, const int32_t *pix_to_face, const float *grad_images, float *grad_R,
+                              float *grad_T, float *grad_light, void *workspace, size_t workspace_bytes, mvr_stream_t stream,
+                              const ViewsBwd *vb) {
   int rc = check_mesh_args(meshes, params);
   if (rc != MVR_OK) return rc;
-  if (!R || !T || !light_dir || !pix_to_face || !grad_images || !grad_R || !grad_T || !workspace)
+  if (!R || !T || !light_dir || !pix_to_face || !grad_images || !workspace)
     return set_err(MVR_ERR_INVALID_ARG, "mvr_render_meshes_backward: null pointer");
   MeshWs ws = mesh_ws_layout(meshes, params, workspace);
   if (workspace_bytes < ws.bytes) return set_err(MVR_ERR_WORKSPACE, "mvr_render_meshes_backward: workspace too small");
@@ -2014,6 +2112,12 @@ int mvr_render_meshes_backward(const mvr_mesh_batch *meshes, const mvr_mesh_para
   }
   HIP_TRY(hipGetLastError());
   const int views_per_block = MVR_BLOCK / 64;
+  if (vb) {
+    hipLaunchKernelGGL(k_mesh_views_backward_finalize, dim3((N + views_per_block - 1) / views_per_block), dim3(MVR_BLOCK), 0, st,
+                       ws.partials, N, n_strips, R, T, vb->azim, vb->elev, vb->dist, vb->azim_used, vb->elev_used, vb->relative,
+                       vb->g_azim, vb->g_elev, vb->g_dist);
+    return hip_check(hipGetLastError(), "k_mesh_views_backward_finalize");
+  }
   hipLaunchKernelGGL(k_mesh_backward_finalize, dim3((N + views_per_block - 1) / views_per_block), dim3(MVR_BLOCK), 0, st,
                      ws.partials, N, n_strips, R, T, grad_R, grad_T, grad_light);
   return hip_check(hipGetLastError(), "k_mesh_backward_finalize");

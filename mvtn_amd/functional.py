@@ -186,10 +186,10 @@ def render_meshes(packed: PackedMeshes, R, T, light_dir, params):
 
 
 class _RenderMeshViews(torch.autograd.Function):
-    """models/renderer.py:79-113 as ONE autograd node: look_at (+ the device-side remedy of ops.py:156-165) ->
-    [camera-position light, :168-169] -> rasterise + shade.  Same kernels as _LookAt / _CameraPosition / _RenderMeshes
-    chained; one node instead of three cuts the host cost of a training step (graph construction, three backward
-    dispatches and the gradient-accumulation kernels between them) from ~470 us to below the GPU time."""
+    """models/renderer.py:79-113 as ONE autograd node and ONE library call per direction
+    (mvr_render_mesh_views_forward / _backward): look_at (+ the device-side remedy of ops.py:156-165) ->
+    [camera-position light, :168-169] -> rasterise + shade.  One node instead of three cuts the host cost of a training
+    step (graph construction, three backward dispatches, the gradient-accumulation kernels between them) below the GPU time."""
 
     @staticmethod
     def forward(ctx, azim, elev, dist, packed, params, light, max_trials, seed, host_status, need_grad):
@@ -201,38 +201,28 @@ class _RenderMeshViews(torch.autograd.Function):
         if azim.numel() != N:
             raise ValueError("azim/elev/dist must have B*V = %d elements" % N)
         dev = azim.device
-        st = _stream()
         ctx.set_materialize_grads(False)   # unused outputs (R, T of the returned cameras) arrive as None, not zeros
         R = torch.empty(N, 3, 3, dtype=torch.float32, device=dev)
         T = torch.empty(N, 3, dtype=torch.float32, device=dev)
         status = torch.empty(N + 2, dtype=torch.int32, device=dev)
-        az_used, el_used = azim, elev
-        if max_trials >= 0:
-            used = torch.empty(2, N, dtype=torch.float32, device=dev)
-            az_used, el_used = used[0], used[1]
-            sp = status.data_ptr() if host_status is None else host_status.data_ptr()
-            _lib.check(lib.mvr_look_at_checked(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), N, int(max_trials),
-                                               int(seed) & 0xFFFFFFFFFFFFFFFF, R.data_ptr(), T.data_ptr(), az_used.data_ptr(),
-                                               el_used.data_ptr(), status[2:].data_ptr(), sp, st), "mvr_look_at_checked")
-        else:
-            _lib.check(lib.mvr_look_at(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), N, R.data_ptr(), T.data_ptr(),
-                                       status[2:].data_ptr(), status.data_ptr(), st), "mvr_look_at")
+        aux = torch.empty(5, N, dtype=torch.float32, device=dev)   # rows 0-1: angles used | rows 2-4 (as (N,3)): relative light
+        aux_p = aux.data_ptr()
         relative = light is None
-        if relative:   # light direction = camera position of the REQUESTED angles (models/renderer.py:168-169)
-            light = torch.empty(N, 3, dtype=torch.float32, device=dev)
-            _lib.check(lib.mvr_camera_position(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), N, light.data_ptr(), st),
-                       "mvr_camera_position")
-        else:
+        if not relative:
             light = _f32c(light)
+        sp = status.data_ptr() if host_status is None else host_status.data_ptr()
         mb = packed.c_struct()
-        ws_bytes = lib.mvr_mesh_workspace_bytes(mb, params)
+        ws_bytes = packed.workspace_bytes(params)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=dev)
         p2f = torch.empty(N, H, W, dtype=torch.int32, device=dev) if need_grad else None
-        _lib.check(lib.mvr_render_meshes_forward(mb, params, R.data_ptr(), T.data_ptr(), light.data_ptr(), images.data_ptr(),
-                                                 _ptr(p2f), ws.data_ptr(), ws_bytes, st), "mvr_render_meshes_forward")
+        _lib.check(lib.mvr_render_mesh_views_forward(mb, params, azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), int(max_trials),
+                                                     int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(None if relative else light),
+                                                     R.data_ptr(), T.data_ptr(), aux_p, aux_p + 4 * N, aux_p + 8 * N,
+                                                     status.data_ptr() + 8, sp, images.data_ptr(), _ptr(p2f), ws.data_ptr(),
+                                                     ws_bytes, _stream()), "mvr_render_mesh_views_forward")
         if need_grad:
-            ctx.save_for_backward(azim, elev, dist, az_used, el_used, R, T, light, p2f, ws)
+            ctx.save_for_backward(azim, elev, dist, aux, R, T, aux if relative else light, p2f, ws)
             ctx.packed, ctx.params, ctx.relative = packed, params, relative
         ctx.mark_non_differentiable(status)
         return images, R, T, status
@@ -240,32 +230,36 @@ class _RenderMeshViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, gR_ext, gT_ext, _gs):
         lib = _lib.load()
-        azim, elev, dist, az_used, el_used, R, T, light, p2f, ws = ctx.saved_tensors
+        azim, elev, dist, aux, R, T, light, p2f, ws = ctx.saved_tensors
         packed, params = ctx.packed, ctx.params
         N = R.shape[0]
         st = _stream()
         dev = R.device
-        gR_c, gT_c = torch.empty(N, 3, 3, dtype=torch.float32, device=dev), torch.empty(N, 3, dtype=torch.float32, device=dev)
-        gL = torch.empty(N, 3, dtype=torch.float32, device=dev) if ctx.relative else None
+        aux_p = aux.data_ptr()
+        light_p = aux_p + 8 * N if ctx.relative else light.data_ptr()
+        bparams = _lib.MeshParams.from_buffer_copy(params)
+        bparams.flags |= _lib.MVR_WORKSPACE_FROM_FORWARD
+        grads = torch.empty(3, N, dtype=torch.float32, device=dev)
+        gp = grads.data_ptr()
+        if g is not None and gR_ext is None and gT_ext is None:   # the training step: everything in one call
+            _lib.check(lib.mvr_render_mesh_views_backward(packed.c_struct(), bparams, azim.data_ptr(), elev.data_ptr(), dist.data_ptr(),
+                                                          aux_p, aux_p + 4 * N, R.data_ptr(), T.data_ptr(), light_p,
+                                                          1 if ctx.relative else 0, p2f.data_ptr(), _f32c(g).data_ptr(), gp, gp + 4 * N,
+                                                          gp + 8 * N, ws.data_ptr(), ws.numel(), st), "mvr_render_mesh_views_backward")
+            return grads[0], grads[1], grads[2], None, None, None, None, None, None, None
+        # somebody also differentiated through the returned cameras (or only through them): chain the three backwards
+        gR_c, gT_c = torch.zeros(N, 3, 3, dtype=torch.float32, device=dev), torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        gL = torch.zeros(N, 3, dtype=torch.float32, device=dev) if ctx.relative else None
         if g is not None:
-            bparams = _lib.MeshParams.from_buffer_copy(params)
-            bparams.flags |= _lib.MVR_WORKSPACE_FROM_FORWARD
-            _lib.check(lib.mvr_render_meshes_backward(packed.c_struct(), bparams, R.data_ptr(), T.data_ptr(), light.data_ptr(),
-                                                      p2f.data_ptr(), _f32c(g).data_ptr(), gR_c.data_ptr(), gT_c.data_ptr(), _ptr(gL),
-                                                      ws.data_ptr(), ws.numel(), st), "mvr_render_meshes_backward")
-        else:
-            gR_c.zero_()
-            gT_c.zero_()
-            if gL is not None:
-                gL.zero_()
-        if gR_ext is not None:   # somebody also differentiated through the returned cameras
+            _lib.check(lib.mvr_render_meshes_backward(packed.c_struct(), bparams, R.data_ptr(), T.data_ptr(), light_p, p2f.data_ptr(),
+                                                      _f32c(g).data_ptr(), gR_c.data_ptr(), gT_c.data_ptr(), _ptr(gL), ws.data_ptr(),
+                                                      ws.numel(), st), "mvr_render_meshes_backward")
+        if gR_ext is not None:
             gR_c = gR_c + gR_ext
         if gT_ext is not None:
             gT_c = gT_c + gT_ext
-        grads = torch.empty(3, N, dtype=torch.float32, device=dev)
-        _lib.check(lib.mvr_look_at_backward(az_used.data_ptr(), el_used.data_ptr(), dist.data_ptr(), N, gR_c.data_ptr(),
-                                            gT_c.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(), st),
-                   "mvr_look_at_backward")
+        _lib.check(lib.mvr_look_at_backward(aux_p, aux_p + 4 * N, dist.data_ptr(), N, gR_c.data_ptr(), gT_c.data_ptr(), gp, gp + 4 * N,
+                                            gp + 8 * N, st), "mvr_look_at_backward")
         if gL is not None:
             g2 = torch.empty(3, N, dtype=torch.float32, device=dev)
             _lib.check(lib.mvr_camera_position_backward(azim.data_ptr(), elev.data_ptr(), dist.data_ptr(), N, gL.data_ptr(),

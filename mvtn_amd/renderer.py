@@ -54,6 +54,8 @@ class MVRenderer(nn.Module):
         self._pending = []  # pinned status words (written by the kernel) of earlier forwards, "device" mode
         self._status_pool = []  # recycled pinned status buffers
         self._light_cache = {}  # (device, direction tuple) -> (1,3) tensor
+        self._color_cache = {}  # colour name -> 3 floats
+        self._params_cache = {}
         self.strip_rows = strip_rows
         # faces_per_pixel > 1 does not change a HardPhongShader image (hard_rgb_blend reads only
         # the nearest face), so any value >= 1 renders identically; points_per_pixel = K > 1 does change
@@ -70,6 +72,15 @@ class MVRenderer(nn.Module):
         else:
             color = torch_color(self.object_color, max_lightness=True)
         return color
+
+    def _named_color(self, name):
+        """torch_color(name, max_lightness=True) as a tuple of floats, remembered (random colours are never cached)."""
+        if name == "random":
+            return tuple(float(c) for c in torch_color(name, max_lightness=True))
+        c = self._color_cache.get(name)
+        if c is None:
+            c = self._color_cache[name] = tuple(float(x) for x in torch_color(name, max_lightness=True))
+        return c
 
     # -- models/renderer.py:162-171 -----------------------------------------------------------
     def light_direction(self, azim, elev, dist):
@@ -156,9 +167,15 @@ class MVRenderer(nn.Module):
                 if self.light_direction_type == "fixed":
                     self._light_cache[key] = light
         n_light = N if light is None else light.shape[0]
-        params = F.mesh_params(self.nb_views, self.image_size, n_light, obj, [float(c) for c in background_color],
-                               cull_backfaces=bool(self.cull_backfaces), perspective_correct=bool(self.perspective_correct),
-                               strip_rows=self.strip_rows)
+        pkey = (n_light, tuple(obj), tuple(float(c) for c in background_color), bool(self.cull_backfaces),
+                bool(self.perspective_correct), self.strip_rows, self.nb_views, self.image_size)
+        params = self._params_cache.get(pkey)
+        if params is None:
+            if len(self._params_cache) > 64:
+                self._params_cache.clear()
+            params = self._params_cache[pkey] = F.mesh_params(self.nb_views, self.image_size, n_light, pkey[1], pkey[2],
+                                                              cull_backfaces=pkey[3], perspective_correct=pkey[4],
+                                                              strip_rows=self.strip_rows)
         if azim.numel() != N:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (packed.n_meshes, self.nb_views))
         # look-at (+ remedy) -> light -> rasterise + shade as ONE autograd node
@@ -205,8 +222,11 @@ class MVRenderer(nn.Module):
         Returns (rendered_images (B, nb_views, 3, H, W) float32, cameras)."""
         if not azim.is_cuda:
             raise RuntimeError("MVRenderer: azim/elev/dist must be CUDA tensors (models/renderer.py hard-codes .cuda() too)")
-        background_color = torch_color(self.background_color, max_lightness=True)
-        color = self.rendering_color(color)
+        background_color = self._named_color(self.background_color)
+        if self.object_color == "custom" or (self.object_color == "random" and self.training):
+            color = self.rendering_color(color)
+        else:   # a fixed named colour: the same floats every call
+            color = self._named_color("white" if self.object_color == "random" else self.object_color)
         if not self.pc_rendering:
             relative = not (self.light_direction_type == "fixed" or (self.light_direction_type == "random" and self.training))
             lights = None if relative else self.light_direction(azim, elev, dist)

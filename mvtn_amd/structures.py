@@ -115,10 +115,22 @@ class PackedMeshes:
                             len(pairs), max(nv), max(nf), vc)
 
     def c_struct(self):
-        return _lib.MeshBatch(self.n_meshes, self.total_verts, self.total_faces, self.max_faces, self.max_verts, 0,
-                              self.verts.data_ptr(), self.faces.data_ptr(), self.vert_off.data_ptr(),
-                              self.face_off.data_ptr(),
-                              self.vert_colors.data_ptr() if self.vert_colors is not None else None)
+        cs = getattr(self, "_cs", None)
+        if cs is None:   # the tensors of a PackedMeshes are never re-assigned: build the C view once
+            cs = self._cs = _lib.MeshBatch(self.n_meshes, self.total_verts, self.total_faces, self.max_faces, self.max_verts, 0,
+                                           self.verts.data_ptr(), self.faces.data_ptr(), self.vert_off.data_ptr(),
+                                           self.face_off.data_ptr(),
+                                           self.vert_colors.data_ptr() if self.vert_colors is not None else None)
+        return cs
+
+    def workspace_bytes(self, params):
+        """mvr_mesh_workspace_bytes for this batch, remembered per (views, image, strip) shape."""
+        key = (params.n_views, params.image_h, params.image_w, params.strip_rows)
+        cache = self.__dict__.setdefault("_ws_bytes", {})
+        n = cache.get(key)
+        if n is None:
+            n = cache[key] = _lib.load().mvr_mesh_workspace_bytes(self.c_struct(), params)
+        return n
 
 
 class _Transform:
