@@ -336,9 +336,11 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_project_verts(MeshPtrs m, int V, 
 // their own; never compiled into libmvr_hip.so.
 __device__ unsigned long long *g_diag = nullptr;
 #define DIAG_STAMP(slot) do { if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] = clock64(); } while (0)
+#define DIAG_PP(view, slot) do { if (threadIdx.x == 0 && g_diag) g_diag[(size_t)(1 << 20) + (size_t)(view) * 8 + (slot)] = clock64(); } while (0)
 #define DIAG_ADD(slot, v) do { if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] += (v); } while (0)
 #else
 #define DIAG_STAMP(slot)
+#define DIAG_PP(view, slot)
 #define DIAG_ADD(slot, v)
 #endif
 
@@ -381,11 +383,18 @@ __device__ __forceinline__ unsigned short face_bin_range(const f3 &v0, const f3 
   ok = ok && xmax >= px_lo && xmin <= px_hi && ymax >= py_lo && ymin <= py_hi;
   unsigned short out = MVR_BIN_NONE;
   if (ok) {
-    int x0, x1, y0, y1;
-    ndc_range(xmin, xmax, W, &x0, &x1);
+    // Only the rows matter for the bins.  (A face that slips between two pixel-centre columns is still listed; the
+    // rasteriser's setup finds no candidate pixel for it.  Not computing the column range saves ~20 instructions per
+    // face of every view in a pre-pass that is bound by VALU issue on its one CU per view.)
+    int y0, y1;
     ndc_range(ymin, ymax, H, &y0, &y1);
-    if (x0 <= x1 && y0 <= y1) {
-      int g0 = (H - 1 - y1) / G, g1 = (H - 1 - y0) / G;  // NDC row index jy <-> image row H-1-jy
+    if (y0 <= y1) {
+      // NDC row index jy <-> image row H-1-jy; rows < 2^15, so the float quotient settles with one correction
+      // (a 32-bit integer division is ~25 VALU instructions, twice per face of every view)
+      const float rG = __builtin_amdgcn_rcpf((float)G);
+      int g0 = (int)((float)(H - 1 - y1) * rG), g1 = (int)((float)(H - 1 - y0) * rG);
+      g0 += ((H - 1 - y1) - g0 * G >= G ? 1 : 0) - ((H - 1 - y1) - g0 * G < 0 ? 1 : 0);
+      g1 += ((H - 1 - y0) - g1 * G >= G ? 1 : 0) - ((H - 1 - y0) - g1 * G < 0 ? 1 : 0);
       out = (unsigned short)(g0 | (g1 << 8));
     }
   }
@@ -438,9 +447,10 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
                                                        const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
                                                        unsigned short *__restrict__ bins, const StripLists sl = StripLists{nullptr, nullptr, nullptr, 0, 0},
                                                        const ViewConsts vc = ViewConsts{nullptr, nullptr, 0}) {
-  __shared__ int s_hist[256], s_near[256], s_cur[256], s_cur_far[256];
+  __shared__ int s_hist[512], s_cur[512];   // [2 g] near faces of row-bin g, [2 g + 1] far faces: ONE atomic per (face, bin)
   float *pl = (float *)smem;   // 3 * nv
-  if (sl.off && threadIdx.x < 256) { s_hist[threadIdx.x] = 0; s_near[threadIdx.x] = 0; }
+  DIAG_PP(n, 0);
+  if (sl.off && threadIdx.x < 512) s_hist[threadIdx.x] = 0;
   const int b = n / V, v = n - b * V;
   const int vo = m.vert_off[b], nv = m.vert_off[b + 1] - vo;
   const int fo = m.face_off[b], nf = m.face_off[b + 1] - fo;
@@ -464,29 +474,57 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
     proj[i] = make_float4(q.x, q.y, q.z, 0.f);
   }
   __syncthreads();
+  DIAG_PP(n, 1);
   const float px_lo = mvr::pix_to_ndc<float>(0, W), px_hi = mvr::pix_to_ndc<float>(W - 1, W);
   const float py_lo = mvr::pix_to_ndc<float>(0, H), py_hi = mvr::pix_to_ndc<float>(H - 1, H);
-  for (int f = threadIdx.x; f < nf; f += MVR_PB_BLOCK) {
+  // the first MVR_PB_KEEP faces of every thread (all of them up to 8192 faces per mesh) keep their bin range, near
+  // flag and vertex indices in registers for the fill pass below; later ones are re-derived there
+  constexpr int MVR_PB_KEEP = 8;
+  unsigned keep_e[MVR_PB_KEEP];   // bin range | near << 16
+  int keep_i[MVR_PB_KEEP][3];
+#pragma unroll
+  for (int k = 0; k < MVR_PB_KEEP; ++k) keep_e[k] = MVR_BIN_NONE;
+  auto bin_face = [&](int f, int &i0, int &i1, int &i2) -> unsigned {
     const int32_t *__restrict__ fc = m.faces + 3 * (size_t)(fo + f);
-    const int i0 = fc[0], i1 = fc[1], i2 = fc[2];
+    i0 = fc[0]; i1 = fc[1]; i2 = fc[2];
     const f3 v0 = {pl[3 * i0], pl[3 * i0 + 1], pl[3 * i0 + 2]};
     const f3 v1 = {pl[3 * i1], pl[3 * i1 + 1], pl[3 * i1 + 2]};
     const f3 v2 = {pl[3 * i2], pl[3 * i2 + 1], pl[3 * i2 + 2]};
-    const unsigned short e = face_bin_range(v0, v1, v2, H, W, G, cull_backfaces, px_lo, px_hi, py_lo, py_hi);
-    bins[(size_t)n * stride + f] = e;
-    if (sl.off && e != MVR_BIN_NONE) {
-      const bool near_face = fminf(fminf(v0.z, v1.z), v2.z) < Tv[2];
-      for (int g = e & 0xff; g <= (e >> 8); ++g) { atomicAdd(&s_hist[g], 1); if (near_face) atomicAdd(&s_near[g], 1); }
+    const unsigned e = face_bin_range(v0, v1, v2, H, W, G, cull_backfaces, px_lo, px_hi, py_lo, py_hi);
+    const bool near_face = fminf(fminf(v0.z, v1.z), v2.z) < Tv[2];
+    return e | (near_face ? 0x10000u : 0u);
+  };
+#pragma unroll
+  for (int k = 0; k < MVR_PB_KEEP; ++k) {
+    const int f = (int)threadIdx.x + k * MVR_PB_BLOCK;
+    if (f < nf) {
+      const unsigned en = bin_face(f, keep_i[k][0], keep_i[k][1], keep_i[k][2]);
+      keep_e[k] = en;
+      const unsigned e = en & 0xffffu;
+      bins[(size_t)n * stride + f] = (unsigned short)e;
+#ifndef MVR_ABL_PP_NO_HIST
+      if (sl.off && e != MVR_BIN_NONE)
+        for (int g = e & 0xff; g <= (int)(e >> 8); ++g) atomicAdd(&s_hist[2 * g + ((en >> 16) ? 0 : 1)], 1);
+#endif
     }
+  }
+  for (int f = (int)threadIdx.x + MVR_PB_KEEP * MVR_PB_BLOCK; f < nf; f += MVR_PB_BLOCK) {
+    int i0, i1, i2;
+    const unsigned en = bin_face(f, i0, i1, i2);
+    const unsigned e = en & 0xffffu;
+    bins[(size_t)n * stride + f] = (unsigned short)e;
+    if (sl.off && e != MVR_BIN_NONE)
+      for (int g = e & 0xff; g <= (int)(e >> 8); ++g) atomicAdd(&s_hist[2 * g + ((en >> 16) ? 0 : 1)], 1);
   }
   if (!sl.off) return;
   __syncthreads();
+  DIAG_PP(n, 2);
   int *off = sl.off + (size_t)n * (sl.n_bins + 1);
   if (threadIdx.x < 64) {   // exclusive scan of the <= 254 bin counts by one wave (4 per lane)
     const int l = threadIdx.x;
     int c[4], tot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { c[k] = (4 * l + k < sl.n_bins) ? s_hist[4 * l + k] : 0; tot += c[k]; }
+    for (int k = 0; k < 4; ++k) { c[k] = (4 * l + k < sl.n_bins) ? s_hist[8 * l + 2 * k] + s_hist[8 * l + 2 * k + 1] : 0; tot += c[k]; }
     int incl = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -499,8 +537,8 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (4 * l + k < sl.n_bins) {
-        const int nn = s_near[4 * l + k];
-        s_cur[4 * l + k] = fits ? run : -1; s_cur_far[4 * l + k] = run + nn; off[4 * l + k] = run;
+        const int nn = s_hist[8 * l + 2 * k];
+        s_cur[8 * l + 2 * k] = fits ? run : -1; s_cur[8 * l + 2 * k + 1] = run + nn; off[4 * l + k] = run;
         sl.front[(size_t)n * sl.n_bins + 4 * l + k] = nn;
       }
       run += c[k];
@@ -508,16 +546,27 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
     if (l == 0) off[sl.n_bins] = fits ? total : -1;
   }
   __syncthreads();
+  DIAG_PP(n, 3);
   if (s_cur[0] < 0) return;   // overflow: the rasteriser scans
   int4 *lst = sl.list + (size_t)n * sl.cap;
-  for (int f = threadIdx.x; f < nf; f += MVR_PB_BLOCK) {
-    const unsigned e = bins[(size_t)n * stride + f];   // this thread's own store above
+  // list entries carry the vertex indices: the rasteriser's setup saves a dependent load
+#pragma unroll
+  for (int k = 0; k < MVR_PB_KEEP; ++k) {
+    const unsigned e = keep_e[k] & 0xffffu;
     if (e == MVR_BIN_NONE) continue;
-    const int32_t *__restrict__ fc = m.faces + 3 * (size_t)(fo + f);
-    const bool near_face = fminf(fminf(pl[3 * fc[0] + 2], pl[3 * fc[1] + 2]), pl[3 * fc[2] + 2]) < Tv[2];
-    const int4 ent = make_int4(f, fc[0], fc[1], fc[2]);   // with the indices: the rasteriser's setup saves a dependent load
-    for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(near_face ? &s_cur[g] : &s_cur_far[g], 1)] = ent;
+    const int4 ent = make_int4((int)threadIdx.x + k * MVR_PB_BLOCK, keep_i[k][0], keep_i[k][1], keep_i[k][2]);
+    for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(&s_cur[2 * g + ((keep_e[k] >> 16) ? 0 : 1)], 1)] = ent;
   }
+  for (int f = (int)threadIdx.x + MVR_PB_KEEP * MVR_PB_BLOCK; f < nf; f += MVR_PB_BLOCK) {
+    int i0, i1, i2;
+    const unsigned en = bin_face(f, i0, i1, i2);
+    const unsigned e = en & 0xffffu;
+    if (e == MVR_BIN_NONE) continue;
+    const int4 ent = make_int4(f, i0, i1, i2);
+    for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(&s_cur[2 * g + ((en >> 16) ? 0 : 1)], 1)] = ent;
+  }
+  __syncthreads();
+  DIAG_PP(n, 4);
 }
 
 __global__ void __launch_bounds__(MVR_PB_BLOCK) k_project_bins_view(MeshPtrs m, int V, int H, int W, int G, int stride,
@@ -538,6 +587,12 @@ __global__ void __launch_bounds__(1024) k_mesh_prepass(MeshPtrs m, int chunks, i
                                                       ViewConsts vc) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int nb_attr = m.B * chunks;
+#ifdef MVR_ABL_PREPASS_NO_NORMALS
+  if ((int)blockIdx.x < nb_attr) return;
+#endif
+#ifdef MVR_ABL_PREPASS_NO_VIEWS
+  if ((int)blockIdx.x >= nb_attr) return;
+#endif
   if ((int)blockIdx.x < nb_attr) vattr_mesh_lds_body(m, blockIdx.x / chunks, blockIdx.x % chunks, smem, vattr, nullptr);
   else project_bins_view_body(m, (int)blockIdx.x - nb_attr, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins, sl, vc);
 }
