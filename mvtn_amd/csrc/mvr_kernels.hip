@@ -1537,62 +1537,133 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_points_raster_shade(PointsArgs a)
 #else
   const int P_eff = a.P;
 #endif
-  // scan: 4 points (one 8-byte vector of row-bin ranges) per lane; the few that can reach this strip are splatted
-  for (int p0 = tid * 4; p0 < P_eff; p0 += MVR_BLOCK * 4) {
-    const uint2 qb = *reinterpret_cast<const uint2 *>(pbin + p0);
-    const unsigned w[2] = {qb.x, qb.y};
+  // scan: 4 points (one 8-byte vector of row-bin ranges) per lane per chunk of 1024.  Only ~7 % of a cloud reaches a
+  // strip, so the hits are first COMPACTED into an LDS list and then splatted with every lane busy (testing them in
+  // place made every wave run the splat code for every point slot: 40 M VALU instructions, 94 % VALU-bound).
+  int *hlist = (int *)(py_tab + TH);                  // shared with the resolve's group list below
+  int *hcnt = hlist + ((size_t)TH * (W >> 2) > 2048 ? (size_t)TH * (W >> 2) : 2048);
+  for (int c0 = 0; c0 < P_eff; c0 += MVR_BLOCK * 8) {   // 2048 points per chunk: both 8-byte vectors are requested together
+    if (tid == 0) *hcnt = 0;
+    __syncthreads();
+    uint2 qb[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
-      const int p = p0 + k;
-      if (e == MVR_BIN_NONE || (e & 0xffu) > g_hi || (e >> 8) < g_lo || p >= a.P) continue;
+    for (int v = 0; v < 2; ++v) {
+      const int p0 = c0 + (v * MVR_BLOCK + tid) * 4;
+      qb[v] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+      if (p0 < P_eff) qb[v] = *reinterpret_cast<const uint2 *>(pbin + p0);
+    }
+    int hp[8], nh = 0;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int p0 = c0 + (v * MVR_BLOCK + tid) * 4;
+      const unsigned w[2] = {qb[v].x, qb[v].y};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+        const bool h = !(e == MVR_BIN_NONE || (e & 0xffu) > g_hi || (e >> 8) < g_lo || p0 + k >= a.P);
+        hp[nh] = p0 + k;      // branch-free append
+        nh += h ? 1 : 0;
+      }
+    }
+    if (nh) {
+      const int base = atomicAdd(hcnt, nh);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (k < nh) hlist[base + k] = hp[k];
+    }
+    __syncthreads();
+    const int n_hit = *hcnt;
+    for (int e = tid; e < n_hit; e += MVR_BLOCK) {
+      const int p = hlist[e];
       const float4 q = pv[p];
       int x0, x1, y0, y1;
       ndc_range(q.x - a.radius, q.x + a.radius, W, &x0, &x1);
       ndc_range(q.y - a.radius, q.y + a.radius, H, &y0, &y1);
       y0 = max(y0, jy_lo); y1 = min(y1, jy_hi);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(q.z + 0.0f) << 32) | (unsigned)p;
       for (int jy = y0; jy <= y1; ++jy) {
         const float dy = q.y - py_tab[jy - jy_lo];
         unsigned long long *krow = keys + (size_t)(jy_hi - jy) * W + (W - 1);
         for (int ix = x0; ix <= x1; ++ix) {
           const float dx = q.x - px_tab[ix];
           const float dd = dx * dx + dy * dy;
-          if (dd < a.r2) {
-            unsigned long long key = ((unsigned long long)__float_as_uint(q.z + 0.0f) << 32) | (unsigned)p;
-            atomicMin(krow - ix, key);
-          }
+          if (dd < a.r2) atomicMin(krow - ix, key);
         }
       }
     }
+    __syncthreads();
   }
   __syncthreads();
   const size_t HW = (size_t)H * W;
   float *__restrict__ img = a.images + (size_t)n * 3 * HW + (size_t)r0 * W;
   int32_t *__restrict__ p2p = a.p2p ? a.p2p + (size_t)n * HW + (size_t)r0 * W : nullptr;
   const float *__restrict__ cols = a.colors ? a.colors + 3 * (size_t)b * a.P : nullptr;
-  int row = tid / W, col = tid - row * W;
-  const int drow = MVR_BLOCK / W, dcol = MVR_BLOCK - drow * W;
-  for (int pix = tid; pix < rows * W; pix += MVR_BLOCK, row += drow, col += dcol) {
-    if (col >= W) { col -= W; ++row; }
+  // colour of one covered pixel: w = 1 - d2 / r2, out = (f w) / max(w, 1e-4) (NormWeightedCompositor, K = 1).  The
+  // quotients go through mvr::div_by with the correctly rounded reciprocals of their divisors (== IEEE division,
+  // 3 instructions instead of ~11; r2 is uniform, max(w, 1e-4) lies in [2^-14, 1] where rcp_rn2 is verified).
+  const float inv_r2w = 1.0f / a.r2w;
+  auto shade_point = [&](unsigned long long key, int pix, float &cr, float &cg, float &cb, int &pi) {
+    pi = (int)(unsigned)(key & 0xffffffffull);
+    const int row = pix / W, col = pix - row * W;
+    const float4 q = pv[pi];
+    const float dx = q.x - px_tab[W - 1 - col], dy = q.y - py_tab[jy_hi - row - jy_lo];
+    const float dd = dx * dx + dy * dy;
+    const float w = 1.0f - mvr::div_by(dd, a.r2w, inv_r2w);
+    const float cum = w < 1e-4f ? 1e-4f : w;  // NormWeightedCompositor kEpsilon clamp
+    const float yc = rcp_rn2((v2f){cum, cum}).x;
+    float f0 = a.obj[0], f1 = a.obj[1], f2 = a.obj[2];
+    if (cols) { f0 = cols[3 * (size_t)pi]; f1 = cols[3 * (size_t)pi + 1]; f2 = cols[3 * (size_t)pi + 2]; }
+    cr = mvr::div_by(f0 * w, cum, yc); cg = mvr::div_by(f1 * w, cum, yc); cb = mvr::div_by(f2 * w, cum, yc);
+  };
+  if ((W & 3) == 0) {
+    // The kernel is bound by its 3 x 4-byte stores per pixel and only ~5 % of the pixels are covered: groups of 4
+    // consecutive pixels without a point are written as three 16-byte stores straight away; the few groups with
+    // a covered pixel are listed in LDS and finished afterwards (dense), also with 16-byte stores.
+    int *glist = hlist;
+    int *gcnt = hcnt;
+    if (tid == 0) *gcnt = 0;
+    __syncthreads();
+    const int n_groups = rows * (W >> 2);
+    const float4 bg4[3] = {make_float4(a.bg[0], a.bg[0], a.bg[0], a.bg[0]), make_float4(a.bg[1], a.bg[1], a.bg[1], a.bg[1]),
+                           make_float4(a.bg[2], a.bg[2], a.bg[2], a.bg[2])};
+    for (int g = tid; g < n_groups; g += MVR_BLOCK) {
+      const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(keys + 4 * g);
+      const ulonglong2 k23 = *reinterpret_cast<const ulonglong2 *>(keys + 4 * g + 2);
+      if ((k01.x & k01.y & k23.x & k23.y) == MVR_KEY_EMPTY) {
+#ifndef MVR_ABL_PTS_NO_STORE
+        *reinterpret_cast<float4 *>(img + 4 * g) = bg4[0];
+        *reinterpret_cast<float4 *>(img + HW + 4 * g) = bg4[1];
+        *reinterpret_cast<float4 *>(img + 2 * HW + 4 * g) = bg4[2];
+        if (p2p) *reinterpret_cast<int4 *>(p2p + 4 * g) = make_int4(-1, -1, -1, -1);
+#endif
+      } else {
+        glist[atomicAdd(gcnt, 1)] = g;
+      }
+    }
+    __syncthreads();
+    const int n_slow = *gcnt;
+    for (int e = tid; e < n_slow; e += MVR_BLOCK) {
+      const int g = glist[e];
+      float cr[4], cg[4], cb[4];
+      int pi[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long key = keys[4 * g + k];
+        cr[k] = a.bg[0]; cg[k] = a.bg[1]; cb[k] = a.bg[2]; pi[k] = -1;
+        if (key != MVR_KEY_EMPTY) shade_point(key, 4 * g + k, cr[k], cg[k], cb[k], pi[k]);
+      }
+      *reinterpret_cast<float4 *>(img + 4 * g) = make_float4(cr[0], cr[1], cr[2], cr[3]);
+      *reinterpret_cast<float4 *>(img + HW + 4 * g) = make_float4(cg[0], cg[1], cg[2], cg[3]);
+      *reinterpret_cast<float4 *>(img + 2 * HW + 4 * g) = make_float4(cb[0], cb[1], cb[2], cb[3]);
+      if (p2p) *reinterpret_cast<int4 *>(p2p + 4 * g) = make_int4(pi[0], pi[1], pi[2], pi[3]);
+    }
+    return;
+  }
+  for (int pix = tid; pix < rows * W; pix += MVR_BLOCK) {   // image width not a multiple of 4: pixel by pixel
     const unsigned long long key = keys[pix];
     float cr = a.bg[0], cg = a.bg[1], cb = a.bg[2];
     int pi = -1;
-    if (key != MVR_KEY_EMPTY) {
-      pi = (int)(unsigned)(key & 0xffffffffull);
-      const float4 q = pv[pi];
-      const float dx = q.x - px_tab[W - 1 - col], dy = q.y - py_tab[jy_hi - row - jy_lo];
-      const float dd = dx * dx + dy * dy;
-      const float w = 1.0f - dd / a.r2w;
-      const float cum = w < 1e-4f ? 1e-4f : w;  // NormWeightedCompositor kEpsilon clamp
-      float f0 = a.obj[0], f1 = a.obj[1], f2 = a.obj[2];
-      if (cols) { f0 = cols[3 * (size_t)pi]; f1 = cols[3 * (size_t)pi + 1]; f2 = cols[3 * (size_t)pi + 2]; }
-      cr = (f0 * w) / cum; cg = (f1 * w) / cum; cb = (f2 * w) / cum;
-    }
-#ifdef MVR_ABL_PTS_NO_STORE
-    if (cr == 123.f) img[pix] = cr;
-#else
+    if (key != MVR_KEY_EMPTY) shade_point(key, pix, cr, cg, cb, pi);
     img[pix] = cr; img[HW + pix] = cg; img[2 * HW + pix] = cb;
-#endif
     if (p2p) p2p[pix] = pi;
   }
 }
@@ -2182,7 +2253,7 @@ static int points_k(const mvr_points_params *p) { return p->points_per_pixel > 0
 
 static int points_strip_rows(const mvr_points_params *p) {
   if (p->strip_rows > 0) return p->strip_rows;
-  int th = 2 * default_strip_rows(p->image_h, p->image_w);   // few LDS bytes besides the keys: taller strips pay (measured)
+  int th = default_strip_rows(p->image_h, p->image_w);   // measured at C4: 6 / 7 / 8 / 10 / 16 rows -> 78 / 73 / 72 / 89 / 87 us
   return th > p->image_h ? p->image_h : th;
 }
 
@@ -2252,7 +2323,8 @@ int mvr_render_points_forward(const mvr_points_params *p, const float *points, c
                      ws.pv, ws.pbin);
   HIP_TRY(hipGetLastError());
   const int K = points_k(p);
-  size_t lds = (size_t)a.TH * a.W * (K > 1 ? 16 : 8) + (size_t)(a.W + a.TH) * 4 + 16;
+  const size_t list_ints = (size_t)a.TH * (a.W / 4) > 2048 ? (size_t)a.TH * (a.W / 4) : 2048;   // hit list / slow-group list
+  size_t lds = (size_t)a.TH * a.W * (K > 1 ? 16 : 8) + (size_t)(a.W + a.TH) * 4 + 16 + (K > 1 ? 0 : (list_ints + 4) * 4);
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
   const void *kern = K > 1 ? (const void *)k_points_raster_topk : (const void *)k_points_raster_shade;
   if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
