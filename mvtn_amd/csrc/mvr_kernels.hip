@@ -844,6 +844,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       gl = a.sl.list + (size_t)n * a.sl.cap + o0;
       gl_n = (strip + 1 < a.sl.n_bins ? off[strip + 1] : off[a.sl.n_bins]) - o0;
       gl_near = a.sl.front[(size_t)n * a.sl.n_bins + strip];
+      if (gl_n <= MVR_RBATCH) gl_near = gl_n;   // one batch holds the whole strip: no second setup / tile pass
     }
   }
   const bool use_list = gl != nullptr;
@@ -922,6 +923,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     for (int seg = 0; seg < (use_list ? 2 : 1); ++seg) {
     const int seg_lo = (use_list && seg == 1) ? gl_near : 0;
     const int seg_hi = use_list ? (seg == 0 ? gl_near : gl_n) : total_hits;
+    if (use_list && seg_hi <= seg_lo) continue;
     const bool hiz = use_list && seg == 1 && gl_near > 0 && seg_hi > seg_lo;
     if (hiz) {
       const int n_tiles = (W + 7) >> 3;
@@ -1428,39 +1430,53 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_views_backward_finalize(cons
                                                                             const float *__restrict__ elev_used, int relative_light,
                                                                             float *__restrict__ g_azim, float *__restrict__ g_elev,
                                                                             float *__restrict__ g_dist) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * (MVR_BLOCK / 64) + (threadIdx.x >> 6);
-  if (n >= N) return;
+  // TWO waves per view: both sum the view's partials; the even wave then runs the look-at chain and the odd wave the
+  // camera-position chain of the relative light — two long f64 dependency chains side by side (in one wave the two
+  // branches would run one after the other).
+  __shared__ float s_light[MVR_BLOCK / 128][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = wave >> 1, role = wave & 1;
+  const int n = blockIdx.x * (MVR_BLOCK / 128) + slot;
+  const bool live = n < N;
   float acc[MVR_NACC];
 #pragma unroll
   for (int k = 0; k < MVR_NACC; ++k) acc[k] = 0.f;
-  for (int s = lane; s < n_strips; s += 64) {
-    const float *p = partials + ((size_t)n * n_strips + s) * MVR_NACC;
+  if (live) {
+    for (int s = lane; s < n_strips; s += 64) {
+      const float *p = partials + ((size_t)n * n_strips + s) * MVR_NACC;
 #pragma unroll
-    for (int k = 0; k < MVR_NACC; ++k) acc[k] += p[k];
+      for (int k = 0; k < MVR_NACC; ++k) acc[k] += p[k];
+    }
   }
 #pragma unroll
   for (int k = 0; k < MVR_NACC; ++k) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
   }
-  if (lane == 0) {
-    float Rm[9], Tv[3];
-    for (int k = 0; k < 9; ++k) Rm[k] = R[9 * (size_t)n + k];
-    for (int k = 0; k < 3; ++k) Tv[k] = T[3 * (size_t)n + k];
-    mvr::fold_camera_center<float>(Rm, Tv, acc + 12, acc, acc + 9);
-    double gr[9], gt[3], ga, ge, gd;
-    for (int k = 0; k < 9; ++k) gr[k] = (double)acc[k];
-    for (int k = 0; k < 3; ++k) gt[k] = (double)acc[9 + k];
-    mvr::look_at_bwd<double>((double)azim_used[n], (double)elev_used[n], (double)dist[n], gr, gt, &ga, &ge, &gd);
-    float fa = (float)ga, fe = (float)ge, fd = (float)gd;
-    if (relative_light) {
+  float fa = 0.f, fe = 0.f, fd = 0.f;
+  if (live && lane == 0) {
+    if (role == 0) {
+      float Rm[9], Tv[3];
+      for (int k = 0; k < 9; ++k) Rm[k] = R[9 * (size_t)n + k];
+      for (int k = 0; k < 3; ++k) Tv[k] = T[3 * (size_t)n + k];
+      mvr::fold_camera_center<float>(Rm, Tv, acc + 12, acc, acc + 9);
+      double gr[9], gt[3], ga, ge, gd;
+      for (int k = 0; k < 9; ++k) gr[k] = (double)acc[k];
+      for (int k = 0; k < 3; ++k) gt[k] = (double)acc[9 + k];
+      mvr::look_at_bwd<double>((double)azim_used[n], (double)elev_used[n], (double)dist[n], gr, gt, &ga, &ge, &gd);
+      fa = (float)ga; fe = (float)ge; fd = (float)gd;
+    } else if (relative_light) {
       const V3<double> gl = {(double)acc[15], (double)acc[16], (double)acc[17]};
       double la, le, ld;
       mvr::camera_position_bwd<double>((double)azim[n], (double)elev[n], (double)dist[n], gl, &la, &le, &ld);
-      fa += (float)la; fe += (float)le; fd += (float)ld;   // two float gradients added, like autograd's accumulation
+      s_light[slot][0] = (float)la; s_light[slot][1] = (float)le; s_light[slot][2] = (float)ld;
     }
-    g_azim[n] = fa; g_elev[n] = fe; g_dist[n] = fd;
+  }
+  __syncthreads();
+  if (live && lane == 0 && role == 0) {   // two float gradients added, like autograd's accumulation
+    g_azim[n] = relative_light ? fa + s_light[slot][0] : fa;
+    g_elev[n] = relative_light ? fe + s_light[slot][1] : fe;
+    g_dist[n] = relative_light ? fd + s_light[slot][2] : fd;
   }
 }
 
@@ -2239,7 +2255,7 @@ static int mesh_backward_impl(const mvr_mesh_batch *meshes, const mvr_mesh_param
   HIP_TRY(hipGetLastError());
   const int views_per_block = MVR_BLOCK / 64;
   if (vb) {
-    hipLaunchKernelGGL(k_mesh_views_backward_finalize, dim3((N + views_per_block - 1) / views_per_block), dim3(MVR_BLOCK), 0, st,
+    hipLaunchKernelGGL(k_mesh_views_backward_finalize, dim3((N + MVR_BLOCK / 128 - 1) / (MVR_BLOCK / 128)), dim3(MVR_BLOCK), 0, st,
                        ws.partials, N, n_strips, R, T, vb->azim, vb->elev, vb->dist, vb->azim_used, vb->elev_used, vb->relative,
                        vb->g_azim, vb->g_elev, vb->g_dist);
     return hip_check(hipGetLastError(), "k_mesh_views_backward_finalize");
