@@ -1090,11 +1090,11 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
         }
         MVR_SET_ROW();
         kp = keys + (__mul24(jy_hi - jy, W) + (W - 1 - ix));
+        v2f px = {px_tab[ix], px_tab[ix + 1]};   // requested one iteration ahead: its LDS latency hides behind the pair math
         while (true) {
           // two horizontally adjacent pixels (ix, ix + 1) per iteration, evaluated with packed f32 instructions;
           // straight-line: the barycentrics of both are always computed, the final "> 0" tests decide (the sign
           // pre-filter of mvr::face_test only skips work, it rejects nothing the final tests would accept)
-          const v2f px = {px_tab[ix], px_tab[ix + 1]};
           const v2f t0 = (px - X1) * A0 - R0, t1 = (px - X2) * A1 - R1, t2 = (px - X0) * A2 - R2;
           v2f a0 = div_by2(t0, sarea, sinv), a1 = div_by2(t1, sarea, sinv), a2 = div_by2(t2, sarea, sinv);
           if (persp) {
@@ -1128,6 +1128,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
             ix += 2;
             kp -= 2;
           }
+          px = (v2f){px_tab[ix], px_tab[ix + 1]};
         }
 #undef MVR_LOAD_FACE
 #undef MVR_SET_ROW
