@@ -1,0 +1,116 @@
+"""Mesh ingestion on the host side of the boundary: what custom_dataset.py obtains from
+`trimesh.load` / `pytorch3d.io.load_obj` before it builds the single-mesh `Meshes` objects the renderer receives
+(custom_dataset.py:100-143, 250-270) — triangle soup from OFF / OBJ files, the dataset's fixed rotation and the
+centre-and-normalise of util.py:437-451.  numpy only; nothing here touches the GPU.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .structures import Meshes
+
+
+def _fan(poly):
+    """Triangle fan of one polygon (what trimesh / PyTorch3D do for the convex polygons of ModelNet / ShapeNet)."""
+    return [(poly[0], poly[k], poly[k + 1]) for k in range(1, len(poly) - 1)]
+
+
+def load_off(path):
+    """(verts (n,3) float64, faces (m,3) int64) of an Object File Format mesh.  Accepts the ModelNet quirk of a header
+    glued to the counts ("OFF490 518 0"), comments, blank lines, colour columns after the indices and polygons of any
+    size (triangulated as a fan)."""
+    with open(path, "r") as fh:
+        tokens = []
+        for line in fh:
+            line = line.split("#", 1)[0].strip()
+            if line:
+                tokens.append(line)
+    if not tokens or not tokens[0].upper().startswith("OFF"):
+        raise ValueError("%s: not an OFF file" % path)
+    head = tokens[0][3:].split()
+    rest = tokens[1:]
+    if len(head) < 3:
+        head = rest[0].split()
+        rest = rest[1:]
+    nv, nf = int(head[0]), int(head[1])
+    if len(rest) < nv + nf:
+        raise ValueError("%s: truncated OFF file" % path)
+    verts = np.array([[float(x) for x in rest[i].split()[:3]] for i in range(nv)], np.float64).reshape(nv, 3)
+    faces = []
+    for i in range(nv, nv + nf):
+        parts = rest[i].split()
+        k = int(parts[0])
+        faces.extend(_fan([int(x) for x in parts[1:1 + k]]))
+    faces = np.array(faces, np.int64).reshape(-1, 3)
+    if faces.size and (faces.min() < 0 or faces.max() >= nv):
+        raise ValueError("%s: face index out of range" % path)
+    return verts, faces
+
+
+def load_obj(path):
+    """(verts (n,3) float64, faces (m,3) int64) of a Wavefront OBJ: `v` and `f` records only (what custom_dataset.py's
+    ShapeNet branch keeps: `faces.verts_idx`), `a/b/c` index triples, negative (relative) indices, polygons as fans."""
+    verts, faces = [], []
+    with open(path, "r") as fh:
+        for line in fh:
+            if line.startswith("v "):
+                verts.append([float(x) for x in line.split()[1:4]])
+            elif line.startswith("f "):
+                idx = []
+                for tok in line.split()[1:]:
+                    i = int(tok.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                faces.extend(_fan(idx))
+    verts = np.array(verts, np.float64).reshape(-1, 3)
+    faces = np.array(faces, np.int64).reshape(-1, 3)
+    if faces.size and (faces.min() < 0 or faces.max() >= len(verts)):
+        raise ValueError("%s: face index out of range" % path)
+    return verts, faces
+
+
+def load_mesh(path):
+    ext = path.rsplit(".", 1)[-1].lower()
+    if ext == "off":
+        return load_off(path)
+    if ext == "obj":
+        return load_obj(path)
+    raise ValueError("unsupported mesh format: %s" % path)
+
+
+def rotation_matrix(axis, theta, in_degrees=True):
+    """util.py:491-506 (Euler-Rodrigues): rotation about `axis` by `theta`."""
+    if in_degrees:
+        theta = math.radians(theta)
+    axis = np.asarray(axis, np.float64)
+    axis = axis / math.sqrt(np.dot(axis, axis))
+    a = math.cos(theta / 2.0)
+    b, c, d = -axis * math.sin(theta / 2.0)
+    aa, bb, cc, dd = a * a, b * b, c * c, d * d
+    bc, ad, ac, ab, bd, cd = b * c, a * d, a * c, a * b, b * d, c * d
+    return np.array([[aa + bb - cc - dd, 2 * (bc + ad), 2 * (bd - ac)],
+                     [2 * (bc - ad), aa + cc - bb - dd, 2 * (cd + ab)],
+                     [2 * (bd + ac), 2 * (cd - ab), aa + dd - bb - cc]])
+
+
+def torch_center_and_normalize(points, p="inf"):
+    """util.py:437-451: subtract the mean, divide by max_i ||x_i||_p (p numeric), the Frobenius norm ("fro") or 1 ("no")."""
+    center = points.mean(0)
+    if p != "fro" and p != "no":
+        scale = torch.max(torch.norm(points - center, p=float(p), dim=1))
+    elif p == "fro":
+        scale = torch.norm(points - center, p=p)
+    else:
+        scale = 1.0
+    return (points - center) * (1.0 / float(scale))
+
+
+def mesh_from_file(path, angle=-90.0, rot_axis=(1, 0, 0), dset_norm=2, flip_faces=False):
+    """One dataset item as custom_dataset.py:100-132 builds it: load, (optionally) swap the winding, rotate by the
+    dataset's fixed angle about x, centre + normalise, wrap as a single-mesh `Meshes` (float32 verts, int64 faces)."""
+    verts, faces = load_mesh(path)
+    if flip_faces:
+        faces = faces[:, ::-1].copy()
+    verts = rotation_matrix(rot_axis, angle).dot(verts.T).T
+    verts = torch_center_and_normalize(torch.from_numpy(verts).to(torch.float), p=dset_norm)
+    return Meshes([verts], [torch.from_numpy(faces)])
