@@ -550,6 +550,30 @@ def test_edge_case_huge_and_tiny_faces(oracle):
         assert (p2f[0] >= 0).mean() > 0.9
 
 
+def test_edge_case_strip_list_overflow_falls_back_to_the_scan(oracle):
+    """400 large overlapping triangles: every face reaches most strips, the per-strip lists of the pre-pass exceed their
+    reserved capacity (3 entries per face + slack), the view is flagged on the device and the rasteriser scans the
+    2-byte bins instead — in several windows of its 256-entry LDS list; the near/far split and the hierarchical-z
+    rejection are off on that path.  A second mesh in the batch keeps its lists: both paths in one launch."""
+    rng = np.random.default_rng(11)
+    n = 400
+    c = rng.uniform(-0.3, 0.3, (n, 1, 3))
+    tri = c + rng.uniform(-0.9, 0.9, (n, 3, 3)) * np.array([1.0, 1.0, 0.15])
+    v_big = tri.reshape(-1, 3).astype(np.float32)
+    f_big = np.arange(3 * n).reshape(-1, 3).astype(np.int64)
+    v_small, f_small = syn.synthetic_mesh("S", 3)
+    az = np.array([[0.0, 77.0], [30.0, 200.0]], np.float32)
+    el = np.array([[0.0, 25.0], [-20.0, 40.0]], np.float32)
+    di = np.full((2, 2), 2.2, np.float32)
+    for size in (224, 96):
+        img, p2f, want = _render_pair(oracle, [v_big, v_small], [f_big, f_small], az, el, di, size)
+        assert int((p2f != want["pix_to_face"]).sum()) == 0, size
+        ok = _well_conditioned_pixels([v_big, v_small], [f_big, f_small], want["pix_to_face"], 2)
+        err = np.abs(img - want["images"]).reshape(4, 3, size, size).max(1)
+        assert err[ok].max() <= TOL_PIXEL
+        assert (p2f[:2] >= 0).mean() > 0.5      # the triangle soup covers most of its views
+
+
 def test_edge_case_nothing_visible_and_large_image(oracle):
     """Object behind / beside the camera -> pure background; a 300^2 image (more than 254 rows: row-bins of 2 strips)."""
     v, f = syn.synthetic_mesh("S", 0)
