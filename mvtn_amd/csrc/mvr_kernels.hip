@@ -44,6 +44,10 @@ typedef V3<float> f3;
 #endif
 #define MVR_RW (MVR_RB / 64)
 #define MVR_RBATCH MVR_RB        // faces set up per batch: one per lane
+#ifndef MVR_TILE_SHIFT
+#define MVR_TILE_SHIFT 2          // hierarchical-z tiles: 4 columns x the strip's rows (2 / 4 / 8 / 16 columns measured; LDS is at the 4-workgroup limit)
+#endif
+#define MVR_TILE_SPAN (32 >> MVR_TILE_SHIFT)   // faces wider than 32 columns are not tested
 #ifndef MVR_RB_WAVES_PER_SIMD
 #define MVR_RB_WAVES_PER_SIMD 4
 #endif
@@ -812,7 +816,7 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
   int *cnt = list + MVR_LIST_CAP;                                              // [0] list entries, [1..] wave totals (32 ints)
   float *px_tab = (float *)(cnt + 32);                                         // W + 1 pixel-centre x coordinates
   float *py_tab = px_tab + (W + 1);                                            // TH pixel-centre y coordinates (NDC row jy_lo + i)
-  unsigned *tz = (unsigned *)(py_tab + TH);                                    // (W + 7) / 8 tile depth bounds (hierarchical z)
+  unsigned *tz = (unsigned *)(py_tab + TH);                                    // depth bound per tile of 2^MVR_TILE_SHIFT columns (hierarchical z)
   __shared__ unsigned short start[MVR_RB];                                  // first record of every lane's run
 
   int n, strip;
@@ -926,13 +930,13 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     if (use_list && seg_hi <= seg_lo) continue;
     const bool hiz = use_list && seg == 1 && gl_near > 0 && seg_hi > seg_lo;
     if (hiz) {
-      const int n_tiles = (W + 7) >> 3;
+      const int n_tiles = (W + (1 << MVR_TILE_SHIFT) - 1) >> MVR_TILE_SHIFT;
       for (int i = tid; i < n_tiles; i += MVR_RB) tz[i] = 0u;
       __syncthreads();
       int col = tid % W;
       const int dcol = MVR_RB % W;
       for (int pix = tid; pix < rows * W; pix += MVR_RB) {
-        atomicMax(&tz[col >> 3], (unsigned)(keys[pix] >> 32));   // empty pixel: 0xFFFFFFFF, nothing is behind it
+        atomicMax(&tz[col >> MVR_TILE_SHIFT], (unsigned)(keys[pix] >> 32));   // empty pixel: 0xFFFFFFFF, nothing is behind it
         col += dcol; if (col >= W) col -= W;
       }
       __syncthreads();
@@ -984,8 +988,8 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
             // interpolated depth >= min vertex depth up to rounding (the barycentrics are positive and sum to 1 within
             // a few ulp; without perspective correction the sum is 1 - kEps/area, hence the area guard there)
             const float zmin = fminf(fminf(fs.v0.z, fs.v1.z), fs.v2.z);
-            const int t0 = (W - 1 - x1) >> 3, t1 = (W - 1 - x0) >> 3;
-            if (t1 - t0 <= 3 && zmin > 1e-3f && (PERSP || fabsf(fs.area) > 1e-3f)) {
+            const int t0 = (W - 1 - x1) >> MVR_TILE_SHIFT, t1 = (W - 1 - x0) >> MVR_TILE_SHIFT;
+            if (t1 - t0 <= MVR_TILE_SPAN && zmin > 1e-3f && (PERSP || fabsf(fs.area) > 1e-3f)) {
               unsigned zm = tz[t0];
               for (int t = t0 + 1; t <= t1; ++t) zm = max(zm, tz[t]);
               if (zmin * (1.0f - 1e-5f) > __uint_as_float(zm)) my_cnt = 0;   // 0xFFFFFFFF (an empty pixel) is a NaN: never true
@@ -2152,7 +2156,7 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
   a.ambient = params->ambient; a.diffuse = params->diffuse; a.specular = params->specular; a.shininess = params->shininess;
   for (int k = 0; k < 3; ++k) { a.obj[k] = params->obj_color[k]; a.bg[k] = params->bg_color[k]; }
   size_t lds = (size_t)TH * W * 8 + (size_t)MVR_RBATCH * (sizeof(FaceCoef) + sizeof(int2)) + (size_t)(MVR_RBATCH + 1) * 4 +
-               (size_t)MVR_LIST_CAP * 4 + 32 * 4 + (size_t)(W + 1 + TH) * 4 + (size_t)((W + 7) / 8) * 4;
+               (size_t)MVR_LIST_CAP * 4 + 32 * 4 + (size_t)(W + 1 + TH) * 4 + (size_t)((W + (1 << MVR_TILE_SHIFT) - 1) >> MVR_TILE_SHIFT) * 4;
 #ifdef MVR_DIAG
   if (const char *pad = getenv("MVR_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
 #endif
