@@ -44,6 +44,9 @@ typedef V3<float> f3;
 #endif
 #define MVR_RW (MVR_RB / 64)
 #define MVR_RBATCH MVR_RB        // faces set up per batch: one per lane
+#ifndef MVR_PTS_LIST_INTS
+#define MVR_PTS_LIST_INTS 2048   // point-kernel hit list (one chunk of 2048 points can hit entirely)
+#endif
 #ifndef MVR_TILE_SHIFT
 #define MVR_TILE_SHIFT 2          // hierarchical-z tiles: 4 columns x the strip's rows (2 / 4 / 8 / 16 columns measured; LDS is at the 4-workgroup limit)
 #endif
@@ -1509,8 +1512,6 @@ __device__ __forceinline__ f3 point_view(const float *Rm, const float *Tv, float
 // 28 times) and gets the conservative range of row-bins its radius-r disc can reach.
 __global__ void __launch_bounds__(MVR_BLOCK) k_points_project(PointsArgs a, float4 *__restrict__ pv, unsigned short *__restrict__ pbin) {
   const int n = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.P) return;
   const int b = n / a.V;
   float Rm[9], Tv[3];
 #pragma unroll
@@ -1518,18 +1519,29 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_points_project(PointsArgs a, floa
 #pragma unroll
   for (int k = 0; k < 3; ++k) Tv[k] = a.T[3 * (size_t)n + k];
   const float sc = 1.0f / a.dist[n];
-  const f3 q = point_view(Rm, Tv, sc, a.points + 3 * ((size_t)b * a.P + p));
-  unsigned short out = MVR_BIN_NONE;
-  if (q.z >= 0.0f && q.x - a.radius <= 1.0f && q.x + a.radius >= -1.0f && q.y - a.radius <= 1.0f && q.y + a.radius >= -1.0f) {
-    int y0, y1;
-    ndc_range(q.y - a.radius, q.y + a.radius, a.H, &y0, &y1);
-    if (y0 <= y1) {
-      int g0 = (a.H - 1 - y1) / a.bin_rows, g1 = (a.H - 1 - y0) / a.bin_rows;
-      out = (unsigned short)(g0 | (g1 << 8));
+  const float rG = __builtin_amdgcn_rcpf((float)a.bin_rows);
+  // 4 points per lane (the view's camera is loaded once per 1024 points); rows < 2^15, so the row-bin quotient is a
+  // float product settled by one correction instead of a 32-bit integer division
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = (blockIdx.x * 4 + k) * MVR_BLOCK + threadIdx.x;
+    if (p >= a.P) break;
+    const f3 q = point_view(Rm, Tv, sc, a.points + 3 * ((size_t)b * a.P + p));
+    unsigned short out = MVR_BIN_NONE;
+    if (q.z >= 0.0f && q.x - a.radius <= 1.0f && q.x + a.radius >= -1.0f && q.y - a.radius <= 1.0f && q.y + a.radius >= -1.0f) {
+      int y0, y1;
+      ndc_range(q.y - a.radius, q.y + a.radius, a.H, &y0, &y1);
+      if (y0 <= y1) {
+        const int r0 = a.H - 1 - y1, r1 = a.H - 1 - y0;
+        int g0 = (int)((float)r0 * rG), g1 = (int)((float)r1 * rG);
+        g0 += (r0 - g0 * a.bin_rows >= a.bin_rows ? 1 : 0) - (r0 - g0 * a.bin_rows < 0 ? 1 : 0);
+        g1 += (r1 - g1 * a.bin_rows >= a.bin_rows ? 1 : 0) - (r1 - g1 * a.bin_rows < 0 ? 1 : 0);
+        out = (unsigned short)(g0 | (g1 << 8));
+      }
     }
+    pv[(size_t)n * a.pstride + p] = make_float4(q.x, q.y, q.z, 0.f);
+    pbin[(size_t)n * a.pstride + p] = out;
   }
-  pv[(size_t)n * a.pstride + p] = make_float4(q.x, q.y, q.z, 0.f);
-  pbin[(size_t)n * a.pstride + p] = out;
 }
 
 __global__ void __launch_bounds__(MVR_BLOCK) k_points_raster_shade(PointsArgs a) {
@@ -1562,7 +1574,7 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_points_raster_shade(PointsArgs a)
   // strip, so the hits are first COMPACTED into an LDS list and then splatted with every lane busy (testing them in
   // place made every wave run the splat code for every point slot: 40 M VALU instructions, 94 % VALU-bound).
   int *hlist = (int *)(py_tab + TH);                  // shared with the resolve's group list below
-  int *hcnt = hlist + ((size_t)TH * (W >> 2) > 2048 ? (size_t)TH * (W >> 2) : 2048);
+  int *hcnt = hlist + ((size_t)TH * (W >> 2) > MVR_PTS_LIST_INTS ? (size_t)TH * (W >> 2) : MVR_PTS_LIST_INTS);
   for (int c0 = 0; c0 < P_eff; c0 += MVR_BLOCK * 8) {   // 2048 points per chunk: both 8-byte vectors are requested together
     if (tid == 0) *hcnt = 0;
     __syncthreads();
@@ -2340,11 +2352,11 @@ int mvr_render_points_forward(const mvr_points_params *p, const float *points, c
   a.radius = (float)p->radius; a.r2 = a.radius * a.radius; a.r2w = (float)(p->radius * p->radius);
   for (int k = 0; k < 3; ++k) { a.obj[k] = p->obj_color[k]; a.bg[k] = p->bg_color[k]; }
   a.bin_rows = bin_rows_for(a.H, a.TH);
-  hipLaunchKernelGGL(k_points_project, dim3((a.P + MVR_BLOCK - 1) / MVR_BLOCK, a.N), dim3(MVR_BLOCK), 0, (hipStream_t)stream, a,
+  hipLaunchKernelGGL(k_points_project, dim3((a.P + 4 * MVR_BLOCK - 1) / (4 * MVR_BLOCK), a.N), dim3(MVR_BLOCK), 0, (hipStream_t)stream, a,
                      ws.pv, ws.pbin);
   HIP_TRY(hipGetLastError());
   const int K = points_k(p);
-  const size_t list_ints = (size_t)a.TH * (a.W / 4) > 2048 ? (size_t)a.TH * (a.W / 4) : 2048;   // hit list / slow-group list
+  const size_t list_ints = (size_t)a.TH * (a.W / 4) > MVR_PTS_LIST_INTS ? (size_t)a.TH * (a.W / 4) : MVR_PTS_LIST_INTS;   // hit list / slow-group list
   size_t lds = (size_t)a.TH * a.W * (K > 1 ? 16 : 8) + (size_t)(a.W + a.TH) * 4 + 16 + (K > 1 ? 0 : (list_ints + 4) * 4);
   if (lds > 160 * 1024) return set_err(MVR_ERR_UNSUPPORTED, "strip does not fit in LDS; lower strip_rows");
   const void *kern = K > 1 ? (const void *)k_points_raster_topk : (const void *)k_points_raster_shade;
