@@ -1337,7 +1337,11 @@ __global__ void __launch_bounds__(MVR_BLOCK, MVR_BWD_WAVES_PER_SIMD) k_mesh_back
   for (int k = 0; k < 3; ++k) cam.Tr[k] = a.T[3 * (size_t)n + k];
   cam.s = a.s;
   const float *lp = a.light + 3 * (size_t)(a.n_light == 1 ? 0 : n);
-  cam.l = {lp[0], lp[1], lp[2]};
+  {   // the light direction is per view: normalise it once here; its normalisation backward runs once in the finalize
+    float idl; bool cl;
+    cam.l = mvr::normalize_rs<float>({lp[0], lp[1], lp[2]}, mvr::kNormalizeEps, &idl, &cl);
+    cam.l_is_unit = true;
+  }
   cam.cc = mvr::camera_center<float>(cam.R, cam.Tr);
   cam.ph = {a.ambient, a.diffuse, a.specular, a.shininess};
   cam.persp = (a.flags & MVR_PERSPECTIVE_CORRECT) != 0;
@@ -1396,10 +1400,20 @@ __global__ void __launch_bounds__(MVR_BLOCK, MVR_BWD_WAVES_PER_SIMD) k_mesh_back
 
 // one 64-lane wave per view: lanes stride over the strips' partials (18 sums), shuffle-reduce, then fold the
 // camera-centre gradient into (gR, gT).
+// acc[15..17] holds the summed gradient w.r.t. the view's UNIT light vector: apply the normalisation backward once
+__device__ __forceinline__ void light_unit_to_raw_grad(const float *__restrict__ light, int n_light, int n, float *g) {
+  const float *lp = light + 3 * (size_t)(n_light == 1 ? 0 : n);
+  float idl; bool cl;
+  const f3 lh = mvr::normalize_rs<float>({lp[0], lp[1], lp[2]}, mvr::kNormalizeEps, &idl, &cl);
+  const f3 gl = mvr::normalize_rs_bwd<float>(lh, idl, cl, {g[0], g[1], g[2]});
+  g[0] = gl.x; g[1] = gl.y; g[2] = gl.z;
+}
+
 __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_backward_finalize(const float *__restrict__ partials, int N, int n_strips,
                                                                       const float *__restrict__ R, const float *__restrict__ T,
                                                                       float *__restrict__ gR, float *__restrict__ gT,
-                                                                      float *__restrict__ gL) {
+                                                                      float *__restrict__ gL, const float *__restrict__ light,
+                                                                      int n_light) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * (MVR_BLOCK / 64) + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -1423,7 +1437,10 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_backward_finalize(const floa
     mvr::fold_camera_center<float>(Rm, Tv, acc + 12, acc, acc + 9);
     for (int k = 0; k < 9; ++k) gR[9 * (size_t)n + k] = acc[k];
     for (int k = 0; k < 3; ++k) gT[3 * (size_t)n + k] = acc[9 + k];
-    if (gL) for (int k = 0; k < 3; ++k) gL[3 * (size_t)n + k] = acc[15 + k];
+    if (gL) {
+      light_unit_to_raw_grad(light, n_light, n, acc + 15);
+      for (int k = 0; k < 3; ++k) gL[3 * (size_t)n + k] = acc[15 + k];
+    }
   }
 }
 
@@ -1437,7 +1454,8 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_views_backward_finalize(cons
                                                                             const float *__restrict__ azim_used,
                                                                             const float *__restrict__ elev_used, int relative_light,
                                                                             float *__restrict__ g_azim, float *__restrict__ g_elev,
-                                                                            float *__restrict__ g_dist) {
+                                                                            float *__restrict__ g_dist, const float *__restrict__ light,
+                                                                            int n_light) {
   // TWO waves per view: both sum the view's partials; the even wave then runs the look-at chain and the odd wave the
   // camera-position chain of the relative light — two long f64 dependency chains side by side (in one wave the two
   // branches would run one after the other).
@@ -1474,6 +1492,7 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_mesh_views_backward_finalize(cons
       mvr::look_at_bwd<double>((double)azim_used[n], (double)elev_used[n], (double)dist[n], gr, gt, &ga, &ge, &gd);
       fa = (float)ga; fe = (float)ge; fd = (float)gd;
     } else if (relative_light) {
+      light_unit_to_raw_grad(light, n_light, n, acc + 15);
       const V3<double> gl = {(double)acc[15], (double)acc[16], (double)acc[17]};
       double la, le, ld;
       mvr::camera_position_bwd<double>((double)azim[n], (double)elev[n], (double)dist[n], gl, &la, &le, &ld);
@@ -2274,11 +2293,11 @@ static int mesh_backward_impl(const mvr_mesh_batch *meshes, const mvr_mesh_param
   if (vb) {
     hipLaunchKernelGGL(k_mesh_views_backward_finalize, dim3((N + MVR_BLOCK / 128 - 1) / (MVR_BLOCK / 128)), dim3(MVR_BLOCK), 0, st,
                        ws.partials, N, n_strips, R, T, vb->azim, vb->elev, vb->dist, vb->azim_used, vb->elev_used, vb->relative,
-                       vb->g_azim, vb->g_elev, vb->g_dist);
+                       vb->g_azim, vb->g_elev, vb->g_dist, light_dir, params->n_light);
     return hip_check(hipGetLastError(), "k_mesh_views_backward_finalize");
   }
   hipLaunchKernelGGL(k_mesh_backward_finalize, dim3((N + views_per_block - 1) / views_per_block), dim3(MVR_BLOCK), 0, st,
-                     ws.partials, N, n_strips, R, T, grad_R, grad_T, grad_light);
+                     ws.partials, N, n_strips, R, T, grad_R, grad_T, grad_light, light_dir, params->n_light);
   return hip_check(hipGetLastError(), "k_mesh_backward_finalize");
 }
 

@@ -389,6 +389,8 @@ template <typename T> struct PixelGradIn {
   V3<T> l, cc;          // light direction, camera centre
   Phong<T> ph;
   bool persp;
+  bool l_is_unit = false;   // `l` is already normalised; acc[15..17] then receives the gradient w.r.t. the UNIT vector and
+                            // the caller applies normalize_rs_bwd once per view (it is linear in that gradient)
 };
 
 template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T px, T py,
@@ -426,7 +428,9 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
   T idn, idl, idv;
   bool cn, cl, cv;
   V3<T> nh = normalize_rs(n, (T)kNormalizeEps, &idn, &cn);
-  V3<T> lh = normalize_rs(cam.l, (T)kNormalizeEps, &idl, &cl);
+  V3<T> lh = cam.l;
+  idl = (T)1; cl = true;
+  if (!cam.l_is_unit) lh = normalize_rs(cam.l, (T)kNormalizeEps, &idl, &cl);
   T cosang = dot(nh, lh);
   bool lit = cosang > (T)0;
   V3<T> view = {cam.cc.x - p.x, cam.cc.y - p.y, cam.cc.z - p.z};
@@ -465,7 +469,7 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
   g_nh = {g_nh.x + g_cos * lh.x, g_nh.y + g_cos * lh.y, g_nh.z + g_cos * lh.z};
   g_lh = {g_lh.x + g_cos * nh.x, g_lh.y + g_cos * nh.y, g_lh.z + g_cos * nh.z};
   V3<T> g_n = normalize_rs_bwd(nh, idn, cn, g_nh);
-  V3<T> g_l = normalize_rs_bwd(lh, idl, cl, g_lh);
+  V3<T> g_l = cam.l_is_unit ? g_lh : normalize_rs_bwd(lh, idl, cl, g_lh);
   // barycentric gradients
   T gw0 = (dot(g_p, X0) + dot(g_n, N0)) + dot(g_tex, c0);
   T gw1 = (dot(g_p, X1) + dot(g_n, N1)) + dot(g_tex, c1);
