@@ -859,6 +859,17 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
     const size_t HW0 = (size_t)H * W;
     float *__restrict__ img0 = a.images + (size_t)n * 3 * HW0 + (size_t)r0 * W;
     int32_t *__restrict__ p2f0 = a.p2f ? a.p2f + (size_t)n * HW0 + (size_t)r0 * W : nullptr;
+    if ((W & 3) == 0) {   // 16-byte stores (rows start 16-byte aligned when W is a multiple of 4)
+      const float4 b0 = make_float4(a.bg[0], a.bg[0], a.bg[0], a.bg[0]), b1 = make_float4(a.bg[1], a.bg[1], a.bg[1], a.bg[1]),
+                   b2 = make_float4(a.bg[2], a.bg[2], a.bg[2], a.bg[2]);
+      for (int g = tid; g < (rows * W) >> 2; g += MVR_RB) {
+        *reinterpret_cast<float4 *>(img0 + 4 * g) = b0;
+        *reinterpret_cast<float4 *>(img0 + HW0 + 4 * g) = b1;
+        *reinterpret_cast<float4 *>(img0 + 2 * HW0 + 4 * g) = b2;
+        if (p2f0) *reinterpret_cast<int4 *>(p2f0 + 4 * g) = make_int4(-1, -1, -1, -1);
+      }
+      return;
+    }
     for (int pix = tid; pix < rows * W; pix += MVR_RB) {
       img0[pix] = a.bg[0]; img0[HW0 + pix] = a.bg[1]; img0[2 * HW0 + pix] = a.bg[2];
       if (p2f0) p2f0[pix] = -1;
