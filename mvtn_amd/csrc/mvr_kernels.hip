@@ -3,17 +3,20 @@
 // Path: models/renderer.py MVRenderer.forward (reference :173-198) -> render_meshes (:65-114) /
 // render_points (:116-151) and their autograd backward.  Design:
 //
-//   mesh forward = 4 launches on the caller's stream
-//     k_normals_accum / k_vattr_finalize : world-space vertex normals once per MESH (not per view)
-//     k_project_verts                    : (view, vertex) -> NDC x,y + view z, 16 B records (L2 resident)
-//     k_mesh_raster_shade                : one workgroup per (view, strip of rows):
-//         scan the mesh's faces in chunks -> bbox/cull -> compact the faces that touch the strip
-//         into an LDS list (wave ballot + one LDS atomic per wave); small faces are rasterised
-//         one lane per face, large faces one wave per face; depth is resolved with a 64-bit LDS
-//         atomicMin on (float_bits(z) << 32 | face) — exactly PyTorch3D's (z, face index) order;
-//         then every pixel of the strip is shaded (Phong + hard blend) from its winning face and
-//         written straight into the planar (B,V,3,H,W) output with coalesced row stores.
+//   mesh forward = 3 launches on the caller's stream
+//     k_look_at            : R, T of all views (+ validity, device-side remedy, relative-light camera positions)
+//     k_mesh_prepass       : workgroups [0, B): world-space vertex normals once per MESH (64-bit fixed-point LDS sums);
+//                            workgroups [B, B+N): one VIEW each: project the vertices (16 B records, L2 resident), 2-byte
+//                            row-bin range per face, per-strip face lists (near faces first), per-view shading constants
+//     k_mesh_raster_shade  : one workgroup per (view, strip of 8 rows), heaviest strips first:
+//         list -> setup (one lane per face: exact candidate range, signed coefficient record in LDS) -> balanced
+//         split of the batch's pixel PAIRS over the lanes -> packed-f32 exact inside test / barycentrics / depth ->
+//         64-bit LDS atomicMin on (float_bits(z) << 32 | face) — exactly PyTorch3D's (z, face index) order;
+//         far faces are rejected against per-tile depth bounds left by the near ones (hierarchical z);
+//         covered pixels are compacted and shaded (Phong + hard blend), planar (B,V,3,H,W) stores.
 //     No per-pixel fragment tensors, no bin tables, no V-fold mesh copies ever touch HBM.
+//   mesh backward = k_mesh_backward (per covered pixel, 18 partial sums per workgroup) + one finalize launch
+//   points        = k_points_project + k_points_raster_shade (hits compacted, 16-byte stores) [+ k_points_raster_topk]
 //
 // wave = 64 lanes; block = 256 threads (4 waves); strips are full image rows so every store
 // instruction writes whole contiguous rows.
