@@ -38,7 +38,7 @@ r = MVRenderer(V, H, pc_rendering=False, light_direction="fixed", rotation_check
 for _ in range(3):
     r(packed, None, ta, te, td)
 nblocks = 8 * ((B * V + 7) // 8) * 64
-buf = torch.zeros(nblocks * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros((1 << 20) + 8 * 4096, dtype=torch.int64, device=dev)   # raster stamps [0, 8 nblocks), pre-pass stamps from 1 << 20
 lib.mvr_diag_set_buffer.argtypes = [ctypes.c_void_p]
 lib.mvr_diag_set_buffer(buf.data_ptr())
 r(packed, None, ta, te, td)

@@ -1,10 +1,10 @@
+# developer scratch: pre-pass time with the vertex-normal work of a mesh split over 1 / 2 / 4 workgroups
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for v in full NO_NORMALS NO_VIEWS; do
-  d=""; [ "$v" != full ] && d="-DMVR_ABL_PREPASS_$v"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math $d -o /tmp/libpp.so mvtn_amd/csrc/mvr_kernels.hip
-  rm -rf /tmp/pp_prof
-  MVR_LIB=/tmp/libpp.so rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp_prof -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
-  f=$(find /tmp/pp_prof -name "*kernel_stats.csv" | head -1)
-  echo "== $v: $(grep k_mesh_prepass $f | awk -F, '{print $(NF-4)}')"
+for v in 6400 1400 700; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -DMVR_NRM_LDS_VERTS=$v -o /tmp/libpp.so mvtn_amd/csrc/mvr_kernels.hip
+  d=/tmp/pp_prof_$v; rm -rf $d
+  MVR_LIB=/tmp/libpp.so rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+  f=$(find $d -name "*kernel_stats.csv" | head -1)
+  echo "== NRM_LDS_VERTS $v: prepass $(grep k_mesh_prepass $f | awk -F, '{print $(NF-4)}')"
 done
