@@ -438,7 +438,9 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_face_bins(MeshPtrs m, int V, int 
 // ranges straight from LDS.  Same arithmetic as k_project_verts + k_face_bins, one launch instead of two and no
 // global gathers for the bins.
 #define MVR_PB_BLOCK 1024
+#ifndef MVR_PB_LDS_VERTS
 #define MVR_PB_LDS_VERTS 12288   // 12288 * 12 B = 144 KiB
+#endif
 // Per-(view, row-bin) face lists (optional, `sl.off != nullptr`): off[n][g] .. off[n][g + 1] delimit, inside
 // list[n * cap ...], the faces whose bounding box can reach row-bin g — the rasteriser then reads its strip's faces
 // directly instead of scanning every face's 2-byte range.  The order inside a list depends on LDS atomics and may
