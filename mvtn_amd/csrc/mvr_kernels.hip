@@ -453,13 +453,28 @@ struct StripLists { int *off; int4 *list; int *front; int cap, n_bins; };   // l
 // Per-view shading constants written by the pre-pass (8 floats per view: normalised light direction, camera centre,
 // 1 / projection scale): uniform data the rasteriser would otherwise recompute in every lane of every workgroup.
 struct ViewConsts { float *out; const float *light; int n_light; };
+// Optional fusion of k_look_at into the pre-pass (mvr_render_mesh_views_forward): every view workgroup evaluates the
+// look-at of ALL views (one per thread) so that it knows, like the single-workgroup kernel, whether the remedy has to
+// re-draw — the counter-based RNG makes every workgroup take the same decisions — and then keeps its own view's R, T.
+// Same device functions, same results as k_look_at; one launch (and its ~5 us) less per forward.
+struct LookAtFuse {
+  const float *azim, *elev, *dist;   // nullptr: R, T are inputs
+  int max_trials; unsigned long long seed;
+  float *R, *T, *azim_used, *elev_used, *cam_pos;   // outputs (this workgroup writes row n)
+  int32_t *view_valid, *status;
+  int N;
+};
 
 __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n, unsigned char *smem, int V, int H, int W, int G,
                                                        int stride, int cull_backfaces, const float *__restrict__ R,
                                                        const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
                                                        unsigned short *__restrict__ bins, const StripLists sl = StripLists{nullptr, nullptr, nullptr, 0, 0},
-                                                       const ViewConsts vc = ViewConsts{nullptr, nullptr, 0}) {
+                                                       const ViewConsts vc = ViewConsts{nullptr, nullptr, 0},
+                                                       const LookAtFuse la = LookAtFuse{nullptr, nullptr, nullptr, 0, 0ull, nullptr, nullptr,
+                                                                                        nullptr, nullptr, nullptr, nullptr, nullptr, 0}) {
   __shared__ int s_hist[512], s_cur[512];   // [2 g] near faces of row-bin g, [2 g + 1] far faces: ONE atomic per (face, bin)
+  __shared__ float s_RT[12];
+  __shared__ int s_bad;
   float *pl = (float *)smem;   // 3 * nv
   DIAG_PP(n, 0);
   if (sl.off && threadIdx.x < 512) s_hist[threadIdx.x] = 0;
@@ -467,14 +482,60 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
   const int vo = m.vert_off[b], nv = m.vert_off[b + 1] - vo;
   const int fo = m.face_off[b], nf = m.face_off[b + 1] - fo;
   float Rm[9], Tv[3];
+  if (la.azim) {
+    for (int trial = 0;; ++trial) {
+      if (threadIdx.x == 0) s_bad = 0;
+      __syncthreads();
+      int bad = 0;
+      for (int i = threadIdx.x; i < la.N; i += MVR_PB_BLOCK) {
+        float a = la.azim[i], e = la.elev[i];
+        if (trial > 0) {
+          a = a + 180.0f * rng_uniform(la.seed, trial, i, 0);
+          e = e + 90.0f * rng_uniform(la.seed, trial, i, 1);
+        }
+        float Ri[9], Ti[3];
+        mvr::look_at<float>(a, e, la.dist[i], Ri, Ti);
+        const bool ok = mvr::rotation_valid<float>(Ri, 1e-6f);
+        bad += ok ? 0 : 1;
+        if (i == n) {   // this workgroup's view: publish (the last trial's values stay)
 #pragma unroll
-  for (int k = 0; k < 9; ++k) Rm[k] = R[9 * (size_t)n + k];
+          for (int k = 0; k < 9; ++k) { s_RT[k] = Ri[k]; la.R[9 * (size_t)n + k] = Ri[k]; }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) Tv[k] = T[3 * (size_t)n + k];
+          for (int k = 0; k < 3; ++k) { s_RT[9 + k] = Ti[k]; la.T[3 * (size_t)n + k] = Ti[k]; }
+          if (la.azim_used) la.azim_used[n] = a;
+          if (la.elev_used) la.elev_used[n] = e;
+          if (la.view_valid) la.view_valid[n] = ok ? 1 : 0;
+          if (trial == 0 && la.cam_pos) {   // relative light: camera position of the REQUESTED angles
+            const f3 c = mvr::camera_position<float>(la.azim[n], la.elev[n], la.dist[n]);
+            la.cam_pos[3 * n] = c.x; la.cam_pos[3 * n + 1] = c.y; la.cam_pos[3 * n + 2] = c.z;
+          }
+        }
+      }
+      if (bad) atomicAdd(&s_bad, bad);
+      __syncthreads();
+      const int nb = s_bad;
+      __syncthreads();
+      if (nb == 0 || la.max_trials < 0 || trial > la.max_trials) {
+        if (n == 0 && threadIdx.x == 0 && la.status) { la.status[0] = trial; la.status[1] = nb; }
+        break;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rm[k] = s_RT[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Tv[k] = s_RT[9 + k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rm[k] = R[9 * (size_t)n + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Tv[k] = T[3 * (size_t)n + k];
+  }
   float4 *__restrict__ proj = proj_all + (size_t)V * vo + (size_t)v * nv;
   if (vc.out && threadIdx.x == 0) {
-    const float *lp = vc.light + 3 * (size_t)(vc.n_light == 1 ? 0 : n);
-    const f3 lh = mvr::normalize<float>({lp[0], lp[1], lp[2]}, mvr::kNormalizeEps);
+    f3 lraw;
+    if (la.azim && la.cam_pos) lraw = mvr::camera_position<float>(la.azim[n], la.elev[n], la.dist[n]);   // = cam_pos[n], written above by another thread
+    else { const float *lp = vc.light + 3 * (size_t)(vc.n_light == 1 ? 0 : n); lraw = {lp[0], lp[1], lp[2]}; }
+    const f3 lh = mvr::normalize<float>(lraw, mvr::kNormalizeEps);
     const f3 cc = mvr::camera_center<float>(Rm, Tv);
     float *o = vc.out + 8 * (size_t)n;
     o[0] = lh.x; o[1] = lh.y; o[2] = lh.z; o[3] = cc.x; o[4] = cc.y; o[5] = cc.z; o[6] = 1.0f / s; o[7] = 0.f;
@@ -596,7 +657,7 @@ __global__ void __launch_bounds__(1024) k_mesh_prepass(MeshPtrs m, int chunks, i
                                                       int cull_backfaces, const float *__restrict__ R,
                                                       const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
                                                       unsigned short *__restrict__ bins, float4 *__restrict__ vattr, StripLists sl,
-                                                      ViewConsts vc) {
+                                                      ViewConsts vc, LookAtFuse la) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int nb_attr = m.B * chunks;
 #ifdef MVR_ABL_PREPASS_NO_NORMALS
@@ -606,7 +667,7 @@ __global__ void __launch_bounds__(1024) k_mesh_prepass(MeshPtrs m, int chunks, i
   if ((int)blockIdx.x >= nb_attr) return;
 #endif
   if ((int)blockIdx.x < nb_attr) vattr_mesh_lds_body(m, blockIdx.x / chunks, blockIdx.x % chunks, smem, vattr, nullptr);
-  else project_bins_view_body(m, (int)blockIdx.x - nb_attr, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins, sl, vc);
+  else project_bins_view_body(m, (int)blockIdx.x - nb_attr, smem, V, H, W, G, stride, cull_backfaces, R, T, s, proj_all, bins, sl, vc, la);
 }
 
 struct RasterArgs {
@@ -2140,9 +2201,19 @@ int mvr_vertex_normals(const mvr_mesh_batch *meshes, float *normals, void *works
   return launch_vattr(meshes, ws, normals, (hipStream_t)stream);
 }
 
+static int mesh_forward_impl(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const float *R, const float *T,
+                             const float *light_dir, float *images, int32_t *pix_to_face, void *workspace,
+                             size_t workspace_bytes, mvr_stream_t stream, const LookAtFuse *fuse);
+
 int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const float *R, const float *T,
                               const float *light_dir, float *images, int32_t *pix_to_face, void *workspace,
                               size_t workspace_bytes, mvr_stream_t stream) {
+  return mesh_forward_impl(meshes, params, R, T, light_dir, images, pix_to_face, workspace, workspace_bytes, stream, nullptr);
+}
+
+static int mesh_forward_impl(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const float *R, const float *T,
+                             const float *light_dir, float *images, int32_t *pix_to_face, void *workspace,
+                             size_t workspace_bytes, mvr_stream_t stream, const LookAtFuse *fuse) {
   int rc = check_mesh_args(meshes, params);
   if (rc != MVR_OK) return rc;
   if (!R || !T || !light_dir || !images || !workspace) return set_err(MVR_ERR_INVALID_ARG, "mvr_render_meshes_forward: null pointer");
@@ -2171,10 +2242,16 @@ int mvr_render_meshes_forward(const mvr_mesh_batch *meshes, const mvr_mesh_param
       HIP_TRY(hipFuncSetAttribute((const void *)k_mesh_prepass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp));
     if (G == TH && n_strips <= 254) sl = StripLists{ws.soff, ws.slist, ws.sfront, ws.slist_cap, n_strips};
     hipLaunchKernelGGL(k_mesh_prepass, dim3(meshes->n_meshes * chunks + N), dim3(1024), lds_pp, st, mp, chunks, V, H, W, G,
-                       ws.bin_stride, cullf, R, T, s, ws.proj, ws.bins, ws.vattr, sl, ViewConsts{ws.vconst, light_dir, params->n_light});
+                       ws.bin_stride, cullf, R, T, s, ws.proj, ws.bins, ws.vattr, sl, ViewConsts{ws.vconst, light_dir, params->n_light},
+                       fuse ? *fuse : LookAtFuse{nullptr, nullptr, nullptr, 0, 0ull, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0});
     vconst = ws.vconst;
     HIP_TRY(hipGetLastError());
   } else {
+    if (fuse) {   // no fused pre-pass for this mesh size: the look-at runs as its own launch
+      hipLaunchKernelGGL(k_look_at, dim3(1), dim3(MVR_BLOCK), 0, st, fuse->azim, fuse->elev, fuse->dist, fuse->N, fuse->max_trials,
+                         fuse->seed, fuse->R, fuse->T, fuse->azim_used, fuse->elev_used, fuse->view_valid, fuse->status, fuse->cam_pos);
+      HIP_TRY(hipGetLastError());
+    }
     rc = launch_vattr(meshes, ws, nullptr, st);
     if (rc != MVR_OK) return rc;
     if (max_verts <= MVR_PB_LDS_VERTS) {
@@ -2238,11 +2315,10 @@ int mvr_render_mesh_views_forward(const mvr_mesh_batch *meshes, const mvr_mesh_p
     return set_err(MVR_ERR_INVALID_ARG, "mvr_render_mesh_views_forward: null pointer");
   const int N = meshes->n_meshes * params->n_views;
   if (!light_dir && params->n_light != N) return set_err(MVR_ERR_INVALID_ARG, "relative light needs n_light == B*V");
-  hipLaunchKernelGGL(k_look_at, dim3(1), dim3(MVR_BLOCK), 0, (hipStream_t)stream, azim, elev, dist, N, (int)max_trials,
-                     (unsigned long long)seed, R, T, azim_used, elev_used, view_valid, status, light_dir ? nullptr : light_used);
-  HIP_TRY(hipGetLastError());
-  return mvr_render_meshes_forward(meshes, params, R, T, light_dir ? light_dir : light_used, images, pix_to_face, workspace,
-                                   workspace_bytes, stream);
+  const LookAtFuse fuse = {azim, elev, dist, (int)max_trials, (unsigned long long)seed, R, T, azim_used, elev_used,
+                           light_dir ? nullptr : light_used, view_valid, status, N};
+  return mesh_forward_impl(meshes, params, R, T, light_dir ? light_dir : light_used, images, pix_to_face, workspace,
+                           workspace_bytes, stream, &fuse);
 }
 
 int mvr_render_meshes_backward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const float *R, const float *T,
