@@ -119,8 +119,14 @@ template <typename T> MVR_HD V3<T> normalize_bwd(const V3<T> &out, T d, bool cla
 // sin/cos (evaluate in double, round once).
 template <typename T> MVR_HD void sincos_deg(T deg, T *s, T *c) {
   T rad = (T)(kPi / 180.0) * deg;
+#if defined(__HIP_DEVICE_COMPILE__)
+  double sd, cd;            // one argument reduction for both (the device library's sincos returns the values of its sin / cos)
+  sincos((double)rad, &sd, &cd);
+  *s = (T)sd; *c = (T)cd;
+#else
   *s = (T)sin((double)rad);
   *c = (T)cos((double)rad);
+#endif
 }
 
 // camera_position_from_spherical_angles (models/renderer.py:168-169)

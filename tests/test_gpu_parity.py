@@ -84,6 +84,13 @@ def test_look_at_bit_exact(oracle):
     assert int(status[0]) == 0 and int(status[1]) == int((~flags).sum()) and int(status[1]) >= 1
     C = F.camera_position_from_spherical_angles(_t(di), _t(el), _t(az))
     assert np.array_equal(C.cpu().numpy(), oracle.camera_position(az, el, di))
+    # a dense sweep: the device evaluates sin and cos of an angle with ONE f64 sincos; it must return what the oracle's
+    # separate libm sin / cos return, for every angle (200 000 random ones + every multiple of 0.25 degree)
+    az2 = np.concatenate([rng.uniform(-720, 720, 200000), np.arange(-360, 360.25, 0.25)]).astype(np.float32)
+    el2 = np.concatenate([rng.uniform(-90, 90, 200000), np.resize(np.arange(-90, 90.25, 0.25), az2.size - 200000)]).astype(np.float32)
+    di2 = np.full(az2.size, 2.2, np.float32)
+    C2 = F.camera_position_from_spherical_angles(_t(di2), _t(el2), _t(az2))
+    assert np.array_equal(C2.cpu().numpy(), oracle.camera_position(az2, el2, di2))
 
 
 def test_vertex_normals(oracle):
