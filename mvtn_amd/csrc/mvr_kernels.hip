@@ -1279,20 +1279,40 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
   for (int pbase = 0; pbase < n_pix; pbase += plist_cap) {
     const int pend = min(n_pix, pbase + plist_cap);
-    for (int p0 = pbase; p0 < pend; p0 += MVR_RB) {   // uniform trip count: ballots need every lane
-      const int pix = p0 + tid;
-      const bool in = pix < pend;
-      const bool covered = in && keys[in ? pix : 0] != MVR_KEY_EMPTY;
-      if (in && !covered) {
-        img[pix] = bg0; img[HW + pix] = bg1; img[2 * HW + pix] = bg2;
-        if (p2f) p2f[pix] = -1;
+    // groups of 8 x 256 pixels: the 8 key reads are issued together and ONE LDS atomic per wave reserves the list slots
+    // of the whole group (one per 256 pixels used to serialise 7 dependent atomic round trips per strip)
+    for (int g0 = pbase; g0 < pend; g0 += 8 * MVR_RB) {
+      unsigned long long kk[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int pix = g0 + k * MVR_RB + tid;
+        kk[k] = pix < pend ? keys[pix] : 0ull;   // 0: "not covered and nothing to store" marker for out-of-range lanes
       }
-      unsigned long long mc = __ballot(covered);
-      if (mc) {
-        int bs = 0;
-        if (lane == 0) bs = atomicAdd(&cnt[0], __popcll(mc));
-        bs = __shfl(bs, 0);
-        if (covered) plist[bs + __popcll(mc & ((1ull << lane) - 1ull))] = pix;
+      int cntk[8], total = 0;
+      unsigned covbits = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int pix = g0 + k * MVR_RB + tid;
+        const bool in = pix < pend;
+        const bool covered = in && kk[k] != MVR_KEY_EMPTY;
+        if (in && !covered) {
+          img[pix] = bg0; img[HW + pix] = bg1; img[2 * HW + pix] = bg2;
+          if (p2f) p2f[pix] = -1;
+        }
+        const unsigned long long mc = __ballot(covered);
+        cntk[k] = __popcll(mc);
+        total += cntk[k];
+        // rank of this lane among the covered lanes of round k, kept in 6 bits per round
+        covbits |= covered ? (1u << k) : 0u;
+        kk[k] = (unsigned long long)__popcll(mc & ((1ull << lane) - 1ull));
+      }
+      int bs = 0;
+      if (lane == 0 && total) bs = atomicAdd(&cnt[0], total);
+      bs = __shfl(bs, 0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (covbits & (1u << k)) plist[bs + (int)kk[k]] = g0 + k * MVR_RB + tid;
+        bs += cntk[k];
       }
     }
     __syncthreads();
