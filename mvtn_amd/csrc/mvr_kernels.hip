@@ -1413,15 +1413,31 @@ __global__ void __launch_bounds__(MVR_BLOCK, MVR_BWD_WAVES_PER_SIMD) k_mesh_back
   // ---- compact the covered pixels of the strip (coverage ~40 %): the gradient arithmetic below then runs dense
   if (tid == 0) s_cnt = 0;
   __syncthreads();
-  for (int p0 = 0; p0 < n_pix; p0 += MVR_BLOCK) {
-    const int pix = p0 + tid;
-    const bool covered = pix < n_pix && p2f[pix < n_pix ? pix : 0] >= 0;
-    const unsigned long long mc = __ballot(covered);
-    if (mc) {
-      int bs = 0;
-      if (lane == 0) bs = atomicAdd(&s_cnt, __popcll(mc));
-      bs = __shfl(bs, 0);
-      if (covered) plist[bs + __popcll(mc & ((1ull << lane) - 1ull))] = pix;
+  // groups of 8 x 256 pixels: the 8 pix_to_face loads are in flight together and ONE LDS atomic per wave reserves the
+  // list slots of the whole group (a 32-row strip used to serialise 28 dependent load -> ballot -> atomic round trips)
+  for (int g0 = 0; g0 < n_pix; g0 += 8 * MVR_BLOCK) {
+    int fk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pix = g0 + k * MVR_BLOCK + tid;
+      fk[k] = pix < n_pix ? p2f[pix] : -1;
+    }
+    int cntk[8], total = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool covered = fk[k] >= 0;
+      const unsigned long long mc = __ballot(covered);
+      cntk[k] = __popcll(mc);
+      total += cntk[k];
+      fk[k] = covered ? __popcll(mc & ((1ull << lane) - 1ull)) : -1;   // rank among the round's covered lanes
+    }
+    int bs = 0;
+    if (lane == 0 && total) bs = atomicAdd(&s_cnt, total);
+    bs = __shfl(bs, 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (fk[k] >= 0) plist[bs + fk[k]] = g0 + k * MVR_BLOCK + tid;
+      bs += cntk[k];
     }
   }
   __syncthreads();
