@@ -1236,7 +1236,9 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
   DIAG_STAMP(1);
 #ifdef MVR_DIAG
   if (threadIdx.x == 0 && g_diag) {
+#ifndef MVR_DIAG_SHADE
     g_diag[(size_t)blockIdx.x * 8 + 3] = t_scan; g_diag[(size_t)blockIdx.x * 8 + 4] = t_small;
+#endif
     g_diag[(size_t)blockIdx.x * 8 + 5] = t_large; g_diag[(size_t)blockIdx.x * 8 + 6] = n_small_tot;
     g_diag[(size_t)blockIdx.x * 8 + 7] = n_large_tot;
   }
@@ -1316,6 +1318,10 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       }
     }
     __syncthreads();
+#ifdef MVR_DIAG_SHADE
+    if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + 3] = clock64() - g_diag[(size_t)blockIdx.x * 8 + 1];
+    unsigned long long tsh0 = clock64();
+#endif
     const int n_cov = cnt[0];
     // ---- shade the covered pixels (dense).  Software-pipelined: the index chain of the NEXT pixel
     //      (LDS list -> LDS key -> face's vertex indices from L2) is issued before the current pixel's
@@ -1354,6 +1360,10 @@ __global__ void __launch_bounds__(MVR_RB, MVR_RB_WAVES_PER_SIMD) k_mesh_raster_s
       img[cur_pix] = rgb.x; img[HW + cur_pix] = rgb.y; img[2 * HW + cur_pix] = rgb.z;
       if (p2f) p2f[cur_pix] = cur_face;
     }
+#ifdef MVR_DIAG_SHADE
+    __syncthreads();
+    if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + 4] = clock64() - tsh0;
+#endif
     if (pend < n_pix) {
       __syncthreads();
       if (tid == 0) cnt[0] = 0;

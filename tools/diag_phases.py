@@ -19,7 +19,7 @@ args = ap.parse_args()
 
 diag = os.path.join(ROOT, "mvtn_amd", "libmvr_hip_diag.so")
 from mvtn_amd import build as b  # noqa: E402
-cmd = ["hipcc"] + b.HIPCC_FLAGS + ["-DMVR_DIAG", "-o", diag, os.path.join(b.CSRC, "mvr_kernels.hip")]
+cmd = ["hipcc"] + b.HIPCC_FLAGS + ["-DMVR_DIAG"] + ([x for x in os.environ.get("MVR_DIAG_EXTRA", "").split() if x]) + ["-o", diag, os.path.join(b.CSRC, "mvr_kernels.hip")]
 subprocess.run(cmd, check=True)
 os.environ["MVR_LIB"] = diag
 
@@ -43,7 +43,7 @@ lib.mvr_diag_set_buffer.argtypes = [ctypes.c_void_p]
 lib.mvr_diag_set_buffer(buf.data_ptr())
 r(packed, None, ta, te, td)
 torch.cuda.synchronize()
-d = buf.cpu().numpy().reshape(-1, 8)
+d = buf.cpu().numpy().reshape(-1, 8)[:nblocks]   # the pre-pass stamps live further up in the same buffer
 d = d[d[:, 2] > 0]
 tot = (d[:, 2] - d[:, 0]).astype(np.float64)
 print("workgroups: %d   cycles/workgroup (s_memtime ticks @100MHz?): mean %.0f  max %.0f" % (len(d), tot.mean(), tot.max()))
