@@ -581,6 +581,22 @@ def test_edge_case_strip_list_overflow_falls_back_to_the_scan(oracle):
         assert (p2f[:2] >= 0).mean() > 0.5      # the triangle soup covers most of its views
 
 
+def test_edge_case_mesh_too_large_for_the_fused_prepass(oracle):
+    """40 962 vertices / 81 920 faces: the projected vertices no longer fit in LDS (limit 12 288), so the forward takes
+    the separate launches (chunked vertex normals, k_project_verts, k_face_bins, no strip lists) and the rasteriser scans
+    the bins in several passes of 8192 faces; batched with a small mesh (ragged batch, max_verts decides the path)."""
+    v_big, f_big = syn.synthetic_mesh(6, 5)
+    v_small, f_small = syn.synthetic_mesh("S", 1)
+    assert len(v_big) > 12288
+    az = np.array([[15.0, 250.0], [100.0, -60.0]], np.float32)
+    el = np.array([[20.0, -35.0], [5.0, 50.0]], np.float32)
+    di = np.full((2, 2), 2.2, np.float32)
+    img, p2f, want = _render_pair(oracle, [v_big, v_small], [f_big, f_small], az, el, di, 96)
+    assert int((p2f != want["pix_to_face"]).sum()) == 0
+    assert np.abs(img - want["images"]).max() <= TOL_PIXEL
+    assert (p2f >= 0).mean() > 0.3
+
+
 def test_edge_case_nothing_visible_and_large_image(oracle):
     """Object behind / beside the camera -> pure background; a 300^2 image (more than 254 rows: row-bins of 2 strips)."""
     v, f = syn.synthetic_mesh("S", 0)
