@@ -487,14 +487,22 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
       if (threadIdx.x == 0) s_bad = 0;
       __syncthreads();
       int bad = 0;
-      for (int i = threadIdx.x; i < la.N; i += MVR_PB_BLOCK) {
-        float a = la.azim[i], e = la.elev[i];
+      // TWO lanes per view: the f64 sin/cos of the elevation (even lane) and of the azimuth (odd lane) are the long
+      // dependency chains of a look-at; side by side they take half the time.  The even lane finishes the view.
+      for (int base = 0; base < la.N; base += MVR_PB_BLOCK / 2) {
+        const int i = base + ((int)threadIdx.x >> 1);
+        const bool live = i < la.N, role_az = (threadIdx.x & 1) != 0;
+        float a = live ? la.azim[i] : 0.f, e = live ? la.elev[i] : 0.f;
         if (trial > 0) {
           a = a + 180.0f * rng_uniform(la.seed, trial, i, 0);
           e = e + 90.0f * rng_uniform(la.seed, trial, i, 1);
         }
+        float sn, cs;
+        mvr::sincos_deg<float>(role_az ? a : e, &sn, &cs);
+        const float sa = __shfl_xor(sn, 1), ca = __shfl_xor(cs, 1);   // even lanes receive the azimuth's pair
+        if (!live || role_az) continue;
         float Ri[9], Ti[3];
-        mvr::look_at<float>(a, e, la.dist[i], Ri, Ti);
+        mvr::look_at_from_position<float>(mvr::camera_position_sc<float>(sn, cs, sa, ca, la.dist[i]), Ri, Ti);
         const bool ok = mvr::rotation_valid<float>(Ri, 1e-6f);
         bad += ok ? 0 : 1;
         if (i == n) {   // this workgroup's view: publish (the last trial's values stay)
@@ -505,8 +513,8 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
           if (la.azim_used) la.azim_used[n] = a;
           if (la.elev_used) la.elev_used[n] = e;
           if (la.view_valid) la.view_valid[n] = ok ? 1 : 0;
-          if (trial == 0 && la.cam_pos) {   // relative light: camera position of the REQUESTED angles
-            const f3 c = mvr::camera_position<float>(la.azim[n], la.elev[n], la.dist[n]);
+          if (trial == 0 && la.cam_pos) {   // relative light: camera position of the REQUESTED angles (= this trial's)
+            const f3 c = mvr::camera_position_sc<float>(sn, cs, sa, ca, la.dist[n]);
             la.cam_pos[3 * n] = c.x; la.cam_pos[3 * n + 1] = c.y; la.cam_pos[3 * n + 2] = c.z;
           }
         }

@@ -130,11 +130,15 @@ template <typename T> MVR_HD void sincos_deg(T deg, T *s, T *c) {
 }
 
 // camera_position_from_spherical_angles (models/renderer.py:168-169)
+// ... from the sines / cosines of the two angles (so that two lanes can evaluate them side by side)
+template <typename T> MVR_HD V3<T> camera_position_sc(T se, T ce, T sa, T ca, T dist) {
+  return {(dist * ce) * sa, dist * se, (dist * ce) * ca};
+}
 template <typename T> MVR_HD V3<T> camera_position(T azim, T elev, T dist) {
   T se, ce, sa, ca;
   sincos_deg(elev, &se, &ce);
   sincos_deg(azim, &sa, &ca);
-  return {(dist * ce) * sa, dist * se, (dist * ce) * ca};
+  return camera_position_sc(se, ce, sa, ca, dist);
 }
 
 // d(position)/d(azim, elev, dist) contracted with g (angles in degrees).
@@ -156,8 +160,11 @@ template <typename T> struct LookAtState {  // what the backward needs
   bool repaired;
 };
 
+template <typename T> MVR_HD void look_at_from_position(const V3<T> &C, T R[9], T Tr[3], LookAtState<T> *st = nullptr);
 template <typename T> MVR_HD void look_at(T azim, T elev, T dist, T R[9], T Tr[3], LookAtState<T> *st = nullptr) {
-  V3<T> C = camera_position(azim, elev, dist);
+  look_at_from_position(camera_position(azim, elev, dist), R, Tr, st);
+}
+template <typename T> MVR_HD void look_at_from_position(const V3<T> &C, T R[9], T Tr[3], LookAtState<T> *st) {
   V3<T> up = {(T)0, (T)1, (T)0};
   V3<T> neg = {(T)0 - C.x, (T)0 - C.y, (T)0 - C.z};
   T dz, nz, dx, nx, dy, ny;
