@@ -345,7 +345,11 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_project_verts(MeshPtrs m, int V, 
 // diagnostic build only (tools/diag_phases.py): per-workgroup phase timestamps, written to a buffer of
 // their own; never compiled into libmvr_hip.so.
 __device__ unsigned long long *g_diag = nullptr;
+#ifdef MVR_DIAG_WALL   // chip-wide 100 MHz clock: comparable across CUs (tools/diag_timeline.py)
+#define DIAG_STAMP(slot) do { if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
 #define DIAG_STAMP(slot) do { if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] = clock64(); } while (0)
+#endif
 #define DIAG_PP(view, slot) do { if (threadIdx.x == 0 && g_diag) g_diag[(size_t)(1 << 20) + (size_t)(view) * 8 + (slot)] = clock64(); } while (0)
 #define DIAG_ADD(slot, v) do { if (threadIdx.x == 0 && g_diag) g_diag[(size_t)blockIdx.x * 8 + (slot)] += (v); } while (0)
 #else

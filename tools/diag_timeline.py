@@ -1,0 +1,41 @@
+"""Developer tool: occupancy timeline of k_mesh_raster_shade from per-workgroup wall-clock stamps (diagnostic build):
+how many workgroups are in flight over time, and how much of the launch is the under-filled tail."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mvtn_amd import build as b
+diag = os.path.join(ROOT, "mvtn_amd", "libmvr_hip_diag.so")
+subprocess.run(["hipcc"] + b.HIPCC_FLAGS + ["-DMVR_DIAG", "-DMVR_DIAG_WALL", "-o", diag, os.path.join(b.CSRC, "mvr_kernels.hip")], check=True)
+os.environ["MVR_LIB"] = diag
+import numpy as np, torch
+from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, synthetic as syn
+lib = _lib.load()
+dev = torch.device("cuda:0")
+B, V, H = 16, 12, 224
+vl, fl = zip(*[syn.synthetic_mesh("M", i) for i in range(B)])
+packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl]), dev)
+az, el, di = syn.spherical_views(V)
+ta, te, td = (torch.from_numpy(np.tile(x, (B, 1))).to(dev) for x in (az, el, di))
+r = MVRenderer(V, H, pc_rendering=False, light_direction="fixed", rotation_check="off").eval()
+for _ in range(3): r(packed, None, ta, te, td)
+buf = torch.zeros((1 << 20) + 8 * 4096, dtype=torch.int64, device=dev)
+lib.mvr_diag_set_buffer.argtypes = [ctypes.c_void_p]
+lib.mvr_diag_set_buffer(buf.data_ptr())
+r(packed, None, ta, te, td)
+torch.cuda.synchronize()
+nblocks = 8 * ((B * V + 7) // 8) * 28
+d = buf.cpu().numpy().reshape(-1, 8)[:nblocks]
+st, en = d[:, 0].astype(np.float64), d[:, 2].astype(np.float64)
+work = en > 0                      # non-empty strips have an end stamp
+t0 = st[st > 0].min()
+tick_us = 0.01                     # wall_clock64: 100 MHz
+st, en = (st - t0) * tick_us, (en - t0) * tick_us
+T = en[work].max()
+print("kernel span (first start -> last end): %.1f us; %d working workgroups, %d empty" % (T, work.sum(), (~work).sum()))
+busy = (en[work] - st[work]).sum()
+print("sum of workgroup lifetimes / (1024 slots x span) = %.1f %%" % (100 * busy / (1024 * T)))
+edges = np.linspace(0, T, 21)
+for a, bb in zip(edges[:-1], edges[1:]):
+    mid = 0.5 * (a + bb)
+    active = ((st[work] <= mid) & (en[work] >= mid)).sum()
+    print("  t = %5.1f us: %4d workgroups in flight" % (mid, active))
