@@ -231,6 +231,17 @@ def main():
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms, "launches_timed": int(cnt[kind])}
     if args.workload == "mesh_fwdbwd" and cnt[2] > 0:
         roofline["backward_kernel_ms"] = ms[2] / cnt[2]
+    # what actually bounds the kernel (profiles/README.md): share of the launch during which the SIMDs' VALU is issuing,
+    # from the committed SQ counter pass of this round (SQ_ACTIVE_INST_VALU quad-cycles / 1024 SIMDs vs SQ_BUSY_CYCLES / 32)
+    try:
+        import glob
+        sq = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.json")))[-1]))
+        k = sq.get(roofline["kernel"])
+        if k and k.get("SQ_BUSY_CYCLES"):
+            roofline["valu_busy_frac"] = k["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (k["SQ_BUSY_CYCLES"] / 32.0)
+            roofline["valu_wave_instructions"] = k["SQ_INSTS_VALU"]
+    except Exception:
+        pass
 
     # ---- optional: the all-gather of rendered views the north_star names (not part of `value`) --------
     gather = None
