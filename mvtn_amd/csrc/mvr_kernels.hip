@@ -121,37 +121,45 @@ __device__ __forceinline__ float rng_uniform(unsigned long long seed, unsigned t
 // (sys.exit) once a re-draw numbered > max_trials is still invalid.  Running this on the device removes
 // the host synchronisation the reference pays on every forward.
 //   status[0] = re-draws performed, status[1] = views still invalid at the end.
-__global__ void __launch_bounds__(MVR_BLOCK) k_look_at(const float *__restrict__ azim, const float *__restrict__ elev,
-                                                       const float *__restrict__ dist, int n, int max_trials,
-                                                       unsigned long long seed, float *__restrict__ R,
-                                                       float *__restrict__ T, float *__restrict__ azim_used,
-                                                       float *__restrict__ elev_used, int32_t *__restrict__ view_valid,
-                                                       int32_t *__restrict__ status, float *__restrict__ cam_pos = nullptr) {
+#define MVR_LA_BLOCK 1024
+__global__ void __launch_bounds__(MVR_LA_BLOCK) k_look_at(const float *__restrict__ azim, const float *__restrict__ elev,
+                                                          const float *__restrict__ dist, int n, int max_trials,
+                                                          unsigned long long seed, float *__restrict__ R,
+                                                          float *__restrict__ T, float *__restrict__ azim_used,
+                                                          float *__restrict__ elev_used, int32_t *__restrict__ view_valid,
+                                                          int32_t *__restrict__ status, float *__restrict__ cam_pos = nullptr) {
   __shared__ int s_bad;
-  if (cam_pos)   // camera position of the requested angles: the reference's "relative" light (models/renderer.py:168-169)
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const f3 c = mvr::camera_position<float>(azim[i], elev[i], dist[i]);
-      cam_pos[3 * i] = c.x; cam_pos[3 * i + 1] = c.y; cam_pos[3 * i + 2] = c.z;
-    }
   for (int trial = 0;; ++trial) {
     if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
     int bad = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      float a = azim[i], e = elev[i];
+    // TWO lanes per view: the f64 sin/cos of the elevation (even lane) and of the azimuth (odd lane) are the long
+    // dependency chains of a look-at; side by side they take half the time.  The even lane finishes the view.
+    for (int base = 0; base < n; base += MVR_LA_BLOCK / 2) {
+      const int i = base + ((int)threadIdx.x >> 1);
+      const bool live = i < n, role_az = (threadIdx.x & 1) != 0;
+      float a = live ? azim[i] : 0.f, e = live ? elev[i] : 0.f;
       if (trial > 0) {
         a = a + 180.0f * rng_uniform(seed, trial, i, 0);
         e = e + 90.0f * rng_uniform(seed, trial, i, 1);
       }
+      float sn, cs;
+      mvr::sincos_deg<float>(role_az ? a : e, &sn, &cs);
+      const float sa = __shfl_xor(sn, 1), ca = __shfl_xor(cs, 1);   // even lanes receive the azimuth's pair
+      if (!live || role_az) continue;
+      const f3 C = mvr::camera_position_sc<float>(sn, cs, sa, ca, dist[i]);
+      if (trial == 0 && cam_pos) {   // camera position of the REQUESTED angles: the reference's "relative" light (:168-169)
+        cam_pos[3 * i] = C.x; cam_pos[3 * i + 1] = C.y; cam_pos[3 * i + 2] = C.z;
+      }
       float Rm[9], Tv[3];
-      mvr::look_at<float>(a, e, dist[i], Rm, Tv);
+      mvr::look_at_from_position<float>(C, Rm, Tv);
 #pragma unroll
       for (int k = 0; k < 9; ++k) R[9 * i + k] = Rm[k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) T[3 * i + k] = Tv[k];
       if (azim_used) azim_used[i] = a;
       if (elev_used) elev_used[i] = e;
-      bool ok = mvr::rotation_valid<float>(Rm, 1e-6f);
+      const bool ok = mvr::rotation_valid<float>(Rm, 1e-6f);
       if (view_valid) view_valid[i] = ok ? 1 : 0;
       bad += ok ? 0 : 1;
     }
@@ -2189,7 +2197,7 @@ int mvr_look_at_checked(const float *azim, const float *elev, const float *dist,
                         uint64_t seed, float *R, float *T, float *azim_used, float *elev_used, int32_t *view_valid,
                         int32_t *status, mvr_stream_t stream) {
   if (!azim || !elev || !dist || !R || !T || n <= 0) return set_err(MVR_ERR_INVALID_ARG, "mvr_look_at: bad argument");
-  hipLaunchKernelGGL(k_look_at, dim3(1), dim3(MVR_BLOCK), 0, (hipStream_t)stream, azim, elev, dist, n, max_trials,
+  hipLaunchKernelGGL(k_look_at, dim3(1), dim3(MVR_LA_BLOCK), 0, (hipStream_t)stream, azim, elev, dist, n, max_trials,
                      (unsigned long long)seed, R, T, azim_used, elev_used, view_valid, status);
   return hip_check(hipGetLastError(), "k_look_at");
 }
@@ -2306,7 +2314,7 @@ static int mesh_forward_impl(const mvr_mesh_batch *meshes, const mvr_mesh_params
     HIP_TRY(hipGetLastError());
   } else {
     if (fuse) {   // no fused pre-pass for this mesh size: the look-at runs as its own launch
-      hipLaunchKernelGGL(k_look_at, dim3(1), dim3(MVR_BLOCK), 0, st, fuse->azim, fuse->elev, fuse->dist, fuse->N, fuse->max_trials,
+      hipLaunchKernelGGL(k_look_at, dim3(1), dim3(MVR_LA_BLOCK), 0, st, fuse->azim, fuse->elev, fuse->dist, fuse->N, fuse->max_trials,
                          fuse->seed, fuse->R, fuse->T, fuse->azim_used, fuse->elev_used, fuse->view_valid, fuse->status, fuse->cam_pos);
       HIP_TRY(hipGetLastError());
     }
