@@ -544,6 +544,7 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
     for (int k = 0; k < 9; ++k) Rm[k] = s_RT[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) Tv[k] = s_RT[9 + k];
+    DIAG_PP(n, 5);
   } else {
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rm[k] = R[9 * (size_t)n + k];

@@ -28,3 +28,5 @@ for k, nm in enumerate(names):
     dt = (d[:, k + 1] - d[:, k]).astype(np.float64)
     print("%-26s mean %7.0f cycles  max %7.0f" % (nm, dt.mean(), dt.max()))
 print("total mean %.0f cycles" % (d[:, 4] - d[:, 0]).mean())
+if (d[:, 5] > 0).all():
+    print("  of which fused look-at (start -> R, T ready): mean %.0f cycles" % (d[:, 5] - d[:, 0]).mean())
