@@ -112,6 +112,7 @@ def test_vertex_normals(oracle):
 @pytest.mark.parametrize("size,specs,V,persp,cull,light,strip", [
     (128, [("M", 0)], 4, True, False, "fixed", 0),                                  # C1
     (224, [("M", 0), ("M", 1)], 12, True, False, "fixed", 0),                       # C2 slice
+    (224, [("L", 2), ("L", 3)], 20, True, False, "fixed", 0),                       # C5 slice: ShapeNet-sized meshes, 20 views
     (224, [("S", 3), ("L", 4), ("soup", 5), ("M", 6)], 6, True, False, "relative", 0),  # ragged + CAD soup
     (224, [("M", 7), ("soup", 8)], 4, False, True, "fixed", 0),                     # 0.4-style switches
     (96, [("S", 9)], 3, True, False, "fixed", 5),                                   # odd strip height
