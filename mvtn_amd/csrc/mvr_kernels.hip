@@ -652,12 +652,15 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
     for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(&s_cur[2 * g + ((keep_e[k] >> 16) ? 0 : 1)], 1)] = ent;
   }
   for (int f = (int)threadIdx.x + MVR_PB_KEEP * MVR_PB_BLOCK; f < nf; f += MVR_PB_BLOCK) {
-    int i0, i1, i2;
-    const unsigned en = bin_face(f, i0, i1, i2);
-    const unsigned e = en & 0xffffu;
+    // faces beyond the register-resident ones (meshes with more than 8192 faces): the bin range is re-read (this
+    // thread's own store), only the near flag is re-derived — not the whole cull / range arithmetic
+    const unsigned e = bins[(size_t)n * stride + f];
     if (e == MVR_BIN_NONE) continue;
+    const int32_t *__restrict__ fc = m.faces + 3 * (size_t)(fo + f);
+    const int i0 = fc[0], i1 = fc[1], i2 = fc[2];
+    const bool near_face = fminf(fminf(pl[3 * i0 + 2], pl[3 * i1 + 2]), pl[3 * i2 + 2]) < Tv[2];
     const int4 ent = make_int4(f, i0, i1, i2);
-    for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(&s_cur[2 * g + ((en >> 16) ? 0 : 1)], 1)] = ent;
+    for (int g = e & 0xff; g <= (int)(e >> 8); ++g) lst[atomicAdd(&s_cur[2 * g + (near_face ? 0 : 1)], 1)] = ent;
   }
   __syncthreads();
   DIAG_PP(n, 4);
