@@ -145,6 +145,27 @@ int mvr_camera_position_backward(const float *azim, const float *elev, const flo
                                  int32_t n, const float *grad_position, float *grad_azim,
                                  float *grad_elev, float *grad_dist, mvr_stream_t stream);
 
+/* ---- mesh hand-over: models/renderer.py:66-77 ---------------------------- */
+
+/* Where the arrays of a `mvr_mesh_batch` sit inside ONE block of `bytes` bytes (every section 256-byte
+ * aligned), so that B host meshes reach HBM in a single copy (the reference issues 2*B `.cuda()` copies,
+ * models/renderer.py:67-68, and packs on the device, :70-77). */
+typedef struct mvr_pack_layout {
+  int32_t n_meshes, total_verts, total_faces, max_verts, max_faces, reserved_;
+  uint64_t verts_at, faces_at, vert_off_at, face_off_at; /* byte offsets inside the block */
+  uint64_t bytes;                                        /* size of the block */
+} mvr_pack_layout;
+
+/* HOST functions (no GPU call).  n_verts / n_faces: (B) sizes of the meshes. */
+int mvr_pack_meshes_layout(int32_t n_meshes, const int32_t *n_verts, const int32_t *n_faces,
+                           mvr_pack_layout *layout);
+/* verts[b]: (n_verts[b],3) f32, faces[b]: (n_faces[b],3) i64 (the dtype `faces_list()` hands over,
+ * models/renderer.py:68), both host memory.  Writes verts, faces narrowed to i32 (LOCAL indices, checked
+ * against [0, n_verts[b])), and both prefix-sum arrays into `block` (host memory, ideally pinned);
+ * the caller copies the block to HBM and points a mvr_mesh_batch into it. */
+int mvr_pack_meshes_host(const mvr_pack_layout *layout, const float *const *verts, const int32_t *n_verts,
+                         const int64_t *const *faces, const int32_t *n_faces, void *block);
+
 /* ---- mesh path: models/renderer.py:65-114 ------------------------------ */
 
 /* Scratch the mesh calls need (vertex attributes, projected vertices, backward partials). */

@@ -36,9 +36,19 @@ class PointsParams(ctypes.Structure):  # struct mvr_points_params
                 ("radius", ctypes.c_double), ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3)]
 
 
+class PackLayout(ctypes.Structure):  # struct mvr_pack_layout
+    _fields_ = [("n_meshes", ctypes.c_int32), ("total_verts", ctypes.c_int32), ("total_faces", ctypes.c_int32),
+                ("max_verts", ctypes.c_int32), ("max_faces", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+                ("verts_at", ctypes.c_uint64), ("faces_at", ctypes.c_uint64), ("vert_off_at", ctypes.c_uint64),
+                ("face_off_at", ctypes.c_uint64), ("bytes", ctypes.c_uint64)]
+
+
 # name -> (restype, argtypes); mirrors include/mvr.h one to one
 _MB, _MP, _PP = ctypes.POINTER(MeshBatch), ctypes.POINTER(MeshParams), ctypes.POINTER(PointsParams)
+_PL = ctypes.POINTER(PackLayout)
 PROTOTYPES = {
+    "mvr_pack_meshes_layout": (ctypes.c_int, [ctypes.c_int32, _vp, _vp, _PL]),
+    "mvr_pack_meshes_host": (ctypes.c_int, [_PL, _vp, _vp, _vp, _vp, _vp]),
     "mvr_version": (ctypes.c_int, []),
     "mvr_last_error": (ctypes.c_char_p, []),
     "mvr_render_mesh_views_forward": (ctypes.c_int, [_MB, _MP, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,

@@ -25,7 +25,7 @@ def _stale(target, sources):
 
 def _sources():
     inc = os.path.join(os.path.dirname(_HERE), "include", "mvr.h")
-    return [os.path.join(CSRC, "mvr_kernels.hip"), os.path.join(CSRC, "mvr_math.h"), inc]
+    return [os.path.join(CSRC, "mvr_kernels.hip"), os.path.join(CSRC, "mvr_math.h"), inc, os.path.join(CSRC, "mvr_pack.cpp")]
 
 
 def build_hip(force=False, verbose=False):
@@ -34,12 +34,21 @@ def build_hip(force=False, verbose=False):
     if not force and not _stale(LIB_PATH, srcs):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0]]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
-    if verbose:
-        print(" ".join(cmd))
+    # the host-only mesh packer is plain C++: g++ builds the object (function multi-versioning for its
+    # narrowing loop), hipcc links it into the one library
+    pack_o = os.path.join(CSRC, "mvr_pack.o")
+    cmds = [["g++", "-O3", "-std=c++17", "-fPIC", "-fvisibility-inlines-hidden", "-c", "-o", pack_o, srcs[3]],
+            [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0], "-Wl," + pack_o]]
+    try:
+        for cmd in cmds:
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("%s failed:\n%s\n%s" % (os.path.basename(cmd[0]), " ".join(cmd), r.stderr))
+            if verbose:
+                print(" ".join(cmd))
+    finally:
+        if os.path.exists(pack_o):
+            os.remove(pack_o)
     return LIB_PATH
 
 

@@ -66,6 +66,8 @@ static int set_err(int code, const char *msg) {
   snprintf(g_err, sizeof(g_err), "%s", msg);
   return code;
 }
+// mvr_pack.cpp (host-only object of the same library) reports through the same message buffer
+extern "C" __attribute__((visibility("hidden"))) void mvr_set_error_(const char *msg) { set_err(0, msg); }
 static int hip_check(hipError_t e, const char *what) {
   if (e == hipSuccess) return MVR_OK;
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));

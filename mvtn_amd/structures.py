@@ -64,6 +64,37 @@ def _mesh_pairs(meshes):
     return [(m.verts_list()[0], m.faces_list()[0]) for m in meshes]
 
 
+def _host_array(x, dtype):
+    """(n,3) contiguous CPU tensor of `dtype` (no copy when the caller's tensor already is one)."""
+    if isinstance(x, torch.Tensor) and x.dtype == dtype and x.device.type == "cpu" and x.dim() == 2 and x.is_contiguous():
+        return x        # what a DataLoader hands over: nothing to do
+    t = x.detach() if torch.is_tensor(x) else torch.as_tensor(x)
+    t = t.to(device="cpu", dtype=dtype).reshape(-1, 3)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_STAGING = {}   # device -> [ring of (pinned uint8 block, event recorded after its last H2D copy), next slot]
+
+
+def _staging_block(nbytes, device, ring=3):
+    """Host block the packer writes.  GPU: a small ring of pinned blocks, each guarded by the event of the
+    copy that last read it (a block is rewritten only after that copy has finished).  CPU: a fresh tensor."""
+    if device.type == "cpu":
+        return torch.empty(nbytes, dtype=torch.uint8), None
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _STAGING.get(key)
+    if st is None:
+        st = _STAGING[key] = [[None] * ring, 0]
+    slot = st[1]
+    st[1] = (slot + 1) % ring
+    ent = st[0][slot]
+    if ent is None or ent[0].numel() < nbytes:
+        ent = st[0][slot] = (torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True), torch.cuda.Event())
+    else:
+        ent[1].synchronize()
+    return ent
+
+
 class PackedMeshes:
     """A batch of meshes resident in HBM in the layout `struct mvr_mesh_batch` describes:
     verts (sum Vn, 3) f32, faces (sum F, 3) i32 LOCAL indices, prefix-sum offsets.  One H2D copy
@@ -84,35 +115,44 @@ class PackedMeshes:
 
     @staticmethod
     def from_meshes(meshes, device, vert_colors=None):
-        """Pack on the host with numpy (zero-copy views of the CPU tensors; torch's CPU reductions cost tens of
-        milliseconds on small integer tensors), then one H2D copy per array."""
-        import numpy as np
+        """The host half of models/renderer.py:66-77: `mvr_pack_meshes_host` writes verts, faces (int64 ->
+        int32, range-checked) and both prefix sums into ONE pinned staging block; one H2D copy moves it and
+        the four arrays are views of that device block (the reference issues 2*B per-mesh `.cuda()` copies)."""
         pairs = _mesh_pairs(meshes)
         if len(pairs) == 0:
             raise ValueError("empty mesh batch")
-        vs = [np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v, dtype=np.float32).reshape(-1, 3) for v, _ in pairs]
-        fs = [np.asarray(f.detach().cpu().numpy() if torch.is_tensor(f) else f).reshape(-1, 3) for _, f in pairs]
-        nv = [int(v.shape[0]) for v in vs]
-        nf = [int(f.shape[0]) for f in fs]
-        if min(nv) <= 0 or min(nf) <= 0:
-            raise ValueError("every mesh needs at least one vertex and one face")
-        for f, n in zip(fs, nv):
-            if int(f.min()) < 0 or int(f.max()) >= n:
-                raise ValueError("face index out of range")
-        verts = torch.from_numpy(np.ascontiguousarray(np.concatenate(vs, 0)))
-        faces = torch.from_numpy(np.concatenate(fs, 0).astype(np.int32))
-        vo = np.zeros(len(pairs) + 1, np.int32)
-        fo = np.zeros(len(pairs) + 1, np.int32)
-        vo[1:] = np.cumsum(nv)
-        fo[1:] = np.cumsum(nf)
+        n = len(pairs)
+        vs = [_host_array(v, torch.float32) for v, _ in pairs]
+        fs = [_host_array(f, torch.int64) for _, f in pairs]
+        nv = (ctypes.c_int32 * n)(*[v.shape[0] for v in vs])
+        nf = (ctypes.c_int32 * n)(*[f.shape[0] for f in fs])
+        lib = _lib.load()
+        lay = _lib.PackLayout()
+        if lib.mvr_pack_meshes_layout(n, nv, nf, ctypes.byref(lay)) != _lib.MVR_OK:
+            raise ValueError(lib.mvr_last_error().decode())
+        device = torch.device(device)
+        block, done = _staging_block(int(lay.bytes), device)
+        vp = (ctypes.c_void_p * n)(*[v.data_ptr() for v in vs])
+        fp = (ctypes.c_void_p * n)(*[f.data_ptr() for f in fs])
+        if lib.mvr_pack_meshes_host(ctypes.byref(lay), vp, nv, fp, nf, block.data_ptr()) != _lib.MVR_OK:
+            raise ValueError(lib.mvr_last_error().decode())
+        if device.type == "cpu":
+            dev_block = block          # a fresh tensor per call (see _staging_block)
+        else:
+            dev_block = block[:int(lay.bytes)].to(device, non_blocking=True)
+            done.record(torch.cuda.current_stream(device))   # the staging block is reusable once this copy has run
+
+        def view(at, count, dtype):
+            return dev_block[at:at + 4 * count].view(dtype)
+        verts = view(int(lay.verts_at), 3 * lay.total_verts, torch.float32).view(-1, 3)
+        faces = view(int(lay.faces_at), 3 * lay.total_faces, torch.int32).view(-1, 3)
+        vo = view(int(lay.vert_off_at), n + 1, torch.int32)
+        fo = view(int(lay.face_off_at), n + 1, torch.int32)
         vc = None
         if vert_colors is not None:  # (B, >=max Vn, 3) padded, as models/renderer.py:76-77 builds it
-            vcn = vert_colors.detach().cpu().numpy() if torch.is_tensor(vert_colors) else np.asarray(vert_colors)
-            vc = torch.from_numpy(np.ascontiguousarray(np.concatenate([vcn[b, :n].reshape(-1, 3) for b, n in enumerate(nv)], 0),
-                                                       dtype=np.float32)).to(device, non_blocking=True)
-        return PackedMeshes(verts.to(device, non_blocking=True), faces.to(device, non_blocking=True),
-                            torch.from_numpy(vo).to(device, non_blocking=True), torch.from_numpy(fo).to(device, non_blocking=True),
-                            len(pairs), max(nv), max(nf), vc)
+            vcs = vert_colors.detach().to("cpu", torch.float32)
+            vc = torch.cat([vcs[b, :v.shape[0]].reshape(-1, 3) for b, v in enumerate(vs)], 0).contiguous().to(device, non_blocking=True)
+        return PackedMeshes(verts, faces, vo, fo, n, int(lay.max_verts), int(lay.max_faces), vc)
 
     def c_struct(self):
         cs = getattr(self, "_cs", None)

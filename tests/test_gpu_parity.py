@@ -221,6 +221,32 @@ def test_mvrenderer_mesh_forward_backward(oracle, light, persp):
         assert rel < 2e-3, (name, got, ref)
 
 
+def test_host_mesh_hand_over_staging_ring():
+    """CPU meshes every forward (the reference's calling convention, models/renderer.py:66-77): the pinned staging
+    blocks are reused round-robin, so queue many forwards with DIFFERENT batches back to back, with no host sync in
+    between, and compare each with the render of the same batch from HBM-resident PackedMeshes."""
+    from mvtn_amd import MVRenderer, Meshes
+    from mvtn_amd.structures import PackedMeshes
+    V, size = 4, 64
+    r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="fixed").eval()
+    batches = []
+    for k in range(7):                       # more batches than ring slots, ragged and of different sizes
+        specs = [("S", k), ("M", 10 + k)] if k % 2 else [("soup", k), ("S", 20 + k), ("S", 30 + k)]
+        vl, fl = _mesh_batch(specs)
+        batches.append([Meshes([v], [f]) for v, f in zip(vl, fl)])
+    views = [tuple(_t(x[:, :V]) for x in _views(len(b), 4, 40 + k)) for k, b in enumerate(batches)]
+    with torch.no_grad():
+        want = [r(PackedMeshes.from_meshes(b, _dev()), None, *v)[0].clone() for b, v in zip(batches, views)]
+        torch.cuda.synchronize()
+        got = []
+        for rep in range(3):
+            for b, v in zip(batches, views):
+                got.append(r(b, None, *v)[0])
+        torch.cuda.synchronize()
+    for i, g in enumerate(got):
+        assert torch.equal(g, want[i % len(batches)]), i
+
+
 def test_refined_reciprocal_is_correctly_rounded_exhaustive():
     """The rasteriser's perspective-correct barycentrics divide by den through y = RN(1/den) (Markstein); y comes
     from v_rcp_f32 + two Newton steps.  Check y == 1.0f / den (IEEE) for EVERY float in [2^-30, 2^24): all 2^23

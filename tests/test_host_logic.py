@@ -168,6 +168,62 @@ def test_packed_meshes_layout():
     assert torch.equal(p.vert_colors[642:642 + len(vl[1])], col[1, :len(vl[1])])
 
 
+def test_pack_meshes_host_c_abi():
+    """mvr_pack_meshes_layout / mvr_pack_meshes_host (host-only C-ABI functions, include/mvr.h): the one staging
+    block holds exactly what the numpy packing gives, sections are 256-byte aligned, bad indices are refused."""
+    from mvtn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    sizes = [(5, 7), (1, 1), (300, 1000), (64, 33)]        # ragged, including a one-vertex degenerate mesh
+    vs = [rng.normal(size=(nv, 3)).astype(np.float32) for nv, _ in sizes]
+    fs = [rng.integers(0, nv, size=(nf, 3)).astype(np.int64) for nv, nf in sizes]
+    fs[2][-1, -1] = sizes[2][0] - 1                          # the largest legal index
+    n = len(sizes)
+    nv = (ctypes.c_int32 * n)(*[s[0] for s in sizes])
+    nf = (ctypes.c_int32 * n)(*[s[1] for s in sizes])
+    lay = _lib.PackLayout()
+    assert lib.mvr_pack_meshes_layout(n, nv, nf, ctypes.byref(lay)) == 0
+    assert (lay.total_verts, lay.total_faces, lay.max_verts, lay.max_faces) == (370, 1041, 300, 1000)
+    ats = [lay.verts_at, lay.faces_at, lay.vert_off_at, lay.face_off_at, lay.bytes]
+    assert all(a % 256 == 0 for a in ats) and ats == sorted(ats) and lay.faces_at >= 370 * 12
+    block = np.full(lay.bytes, 0xAB, np.uint8)
+    vp = (ctypes.c_void_p * n)(*[v.ctypes.data for v in vs])
+    fp = (ctypes.c_void_p * n)(*[f.ctypes.data for f in fs])
+    assert lib.mvr_pack_meshes_host(ctypes.byref(lay), vp, nv, fp, nf, block.ctypes.data) == 0
+    assert np.array_equal(block[lay.verts_at:lay.verts_at + 370 * 12].view(np.float32).reshape(-1, 3), np.concatenate(vs))
+    assert np.array_equal(block[lay.faces_at:lay.faces_at + 1041 * 12].view(np.int32).reshape(-1, 3), np.concatenate(fs).astype(np.int32))
+    assert block[lay.vert_off_at:lay.vert_off_at + 20].view(np.int32).tolist() == [0, 5, 6, 306, 370]
+    assert block[lay.face_off_at:lay.face_off_at + 20].view(np.int32).tolist() == [0, 7, 8, 1008, 1041]
+    for bad in (-1, 300, 2 ** 31, 2 ** 40 + 3, -2 ** 33):   # out of range, including values whose low word looks legal
+        g = fs[2].copy()
+        g[17, 1] = bad
+        fp2 = (ctypes.c_void_p * n)(fs[0].ctypes.data, fs[1].ctypes.data, g.ctypes.data, fs[3].ctypes.data)
+        assert lib.mvr_pack_meshes_host(ctypes.byref(lay), vp, nv, fp2, nf, block.ctypes.data) == 1, bad
+        assert b"mesh 2" in lib.mvr_last_error()
+    nv0 = (ctypes.c_int32 * n)(5, 0, 300, 64)
+    assert lib.mvr_pack_meshes_layout(n, nv0, nf, ctypes.byref(lay)) == 1 and b"mesh 1" in lib.mvr_last_error()
+    assert lib.mvr_pack_meshes_layout(0, nv, nf, ctypes.byref(lay)) == 1
+
+
+def test_packed_meshes_accepts_what_callers_hand_over():
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    v, f = syn.synthetic_mesh("S", 0)
+    want = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v)], [torch.from_numpy(f)]), "cpu")
+    # non-contiguous vertices, int32 faces, float64 vertices, numpy inputs: converted on the way in
+    vt = torch.from_numpy(np.ascontiguousarray(v.T)).T
+    for vv, ff in ((vt, torch.from_numpy(f)), (torch.from_numpy(v).double(), torch.from_numpy(f).int()), (v, f)):
+        class One:          # a single-mesh object with the two accessors the reference uses (models/renderer.py:67-68)
+            def verts_list(self, vv=vv): return [vv]
+            def faces_list(self, ff=ff): return [ff]
+        got = PackedMeshes.from_meshes([One()], "cpu")
+        assert torch.equal(got.verts, want.verts) and torch.equal(got.faces, want.faces)
+        assert got.vert_off.tolist() == [0, 642] and got.face_off.tolist() == [0, 1280]
+    with pytest.raises(ValueError):
+        PackedMeshes.from_meshes([], "cpu")
+    with pytest.raises(ValueError):
+        PackedMeshes.from_meshes(Meshes([torch.zeros(0, 3)], [torch.zeros(1, 3, dtype=torch.int64)]), "cpu")
+
+
 def test_cameras_object():
     from mvtn_amd.structures import Cameras
     from oracle import oracle as orc
