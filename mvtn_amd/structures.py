@@ -76,6 +76,17 @@ def _host_array(x, dtype):
 _STAGING = {}   # device -> [ring of (pinned uint8 block, event recorded after its last H2D copy), next slot]
 
 
+_COPY_STREAMS = {}
+
+
+def _copy_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _COPY_STREAMS.get(key)
+    if st is None:
+        st = _COPY_STREAMS[key] = torch.cuda.Stream(device)
+    return st
+
+
 def _staging_block(nbytes, device, ring=3):
     """Host block the packer writes.  GPU: a small ring of pinned blocks, each guarded by the event of the
     copy that last read it (a block is rewritten only after that copy has finished).  CPU: a fresh tensor."""
@@ -139,8 +150,14 @@ class PackedMeshes:
         if device.type == "cpu":
             dev_block = block          # a fresh tensor per call (see _staging_block)
         else:
-            dev_block = block[:int(lay.bytes)].to(device, non_blocking=True)
-            done.record(torch.cuda.current_stream(device))   # the staging block is reusable once this copy has run
+            # the copy runs on a side stream, so that it overlaps the kernels of the PREVIOUS forward still queued
+            # on the caller's stream (the host runs ahead of the GPU); the caller's stream then waits for it
+            cur, side = torch.cuda.current_stream(device), _copy_stream(device)
+            with torch.cuda.stream(side):
+                dev_block = block[:int(lay.bytes)].to(device, non_blocking=True)
+                done.record(side)                  # the staging block is reusable once this copy has run
+            cur.wait_event(done)
+            dev_block.record_stream(cur)           # allocated on the side stream's pool, read on the caller's
 
         def view(at, count, dtype):
             return dev_block[at:at + 4 * count].view(dtype)
