@@ -247,6 +247,27 @@ int mvr_render_points_backward(const mvr_points_params *params, const float *poi
                                float *grad_dist, void *workspace, size_t workspace_bytes,
                                mvr_stream_t stream);
 
+/* ---- the step after the renderer: ops.py:168-176 (run_mvtn.py:186-187) ---- */
+
+/* regualarize_rendered_views = dropout2d over whole views (ops.py:170-171: on the 5-D (B,V,C,H,W) tensor the keep
+ * mask is (B,V,1,1,1)) + applied_transforms (ops.py:138-146) per image: RandomHorizontalFlip (util.py:168-196),
+ * ReplicationPad2d(pad), RandomCrop(H) (util.py:199-242) — applied in ONE pass:
+ *   out[n,c,i,j] = scale[n] * images[n,c, clamp(i + crop_i[n] - pad), flip_n(clamp(j + crop_j[n] - pad))]
+ * images, out: (n_images, channels, h, w) f32, distinct buffers.  Per image n (memory order of `images`):
+ *   scale  (n_images) f32: 0 for a dropped view, 1/(1-p) otherwise; NULL = no dropout
+ *   flip   (n_images) u8 : non-zero = mirror the columns;           NULL = no flips
+ *   crop_i, crop_j (n_images) i32 in [0, 2*pad]: offsets of the crop window in the padded image (both or neither;
+ *          NULL = centred window = no shift).
+ * The caller draws mask / flips / offsets (torch generators, in the reference's order); the kernels apply them.
+ * Backward: grad_images[n,c,y,x] = scale[n] * sum of grad_out over the output pixels that read (y,x), summed in a
+ * fixed order (bit-reproducible; the reference's replication-pad backward uses atomics). */
+int mvr_regularize_views_forward(const float *images, int32_t n_images, int32_t channels, int32_t h, int32_t w,
+                                 const float *scale, const uint8_t *flip, const int32_t *crop_i,
+                                 const int32_t *crop_j, int32_t pad, float *out, mvr_stream_t stream);
+int mvr_regularize_views_backward(const float *grad_out, int32_t n_images, int32_t channels, int32_t h, int32_t w,
+                                  const float *scale, const uint8_t *flip, const int32_t *crop_i,
+                                  const int32_t *crop_j, int32_t pad, float *grad_images, mvr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,8 @@ def _stale(target, sources):
 
 def _sources():
     inc = os.path.join(os.path.dirname(_HERE), "include", "mvr.h")
-    return [os.path.join(CSRC, "mvr_kernels.hip"), os.path.join(CSRC, "mvr_math.h"), inc, os.path.join(CSRC, "mvr_pack.cpp")]
+    return [os.path.join(CSRC, "mvr_kernels.hip"), os.path.join(CSRC, "mvr_math.h"), inc, os.path.join(CSRC, "mvr_pack.cpp"),
+            os.path.join(CSRC, "mvr_regularize.hip")]
 
 
 def build_hip(force=False, verbose=False):
@@ -38,7 +39,7 @@ def build_hip(force=False, verbose=False):
     # narrowing loop), hipcc links it into the one library
     pack_o = os.path.join(CSRC, "mvr_pack.o")
     cmds = [["g++", "-O3", "-std=c++17", "-fPIC", "-fvisibility-inlines-hidden", "-c", "-o", pack_o, srcs[3]],
-            [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0], "-Wl," + pack_o]]
+            [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0], srcs[4], "-Wl," + pack_o]]
     try:
         for cmd in cmds:
             r = subprocess.run(cmd, capture_output=True, text=True)

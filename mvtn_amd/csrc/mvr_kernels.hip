@@ -1420,6 +1420,7 @@ struct MeshBwdArgs {
 #ifndef MVR_BWD_STRIP_MULT
 #define MVR_BWD_STRIP_MULT 4
 #endif
+#define MVR_BWD_SCAN_GROUPS (64 / MVR_WAVES)   // (group, wave) counts one wave can scan at a time
 #ifndef MVR_BWD_WAVES_PER_SIMD
 #define MVR_BWD_WAVES_PER_SIMD 3   // 168 VGPRs without spills; 4 (128) spills 42 registers and doubles the time
 #endif
@@ -1427,7 +1428,7 @@ __global__ void __launch_bounds__(MVR_BLOCK, MVR_BWD_WAVES_PER_SIMD) k_mesh_back
   extern __shared__ __align__(16) unsigned char smem[];
   int *plist = (int *)smem;                               // rows * W covered-pixel indices
   __shared__ float s_part[MVR_WAVES][MVR_NACC];
-  __shared__ int s_cnt;
+  __shared__ int s_goff[MVR_BWD_SCAN_GROUPS * MVR_WAVES + 1];
   int n, strip;
   decode_block(blockIdx.x, a.n_strips, a.views_per_xcd, &n, &strip);
   if (n >= a.N) return;
@@ -1446,38 +1447,55 @@ __global__ void __launch_bounds__(MVR_BLOCK, MVR_BWD_WAVES_PER_SIMD) k_mesh_back
   const int32_t *__restrict__ p2f = a.p2f + (size_t)n * HW + (size_t)r0 * W;
   const float *__restrict__ g = a.gimg + (size_t)n * 3 * HW + (size_t)r0 * W;
 
-  // ---- compact the covered pixels of the strip (coverage ~40 %): the gradient arithmetic below then runs dense
-  if (tid == 0) s_cnt = 0;
-  __syncthreads();
-  // groups of 8 x 256 pixels: the 8 pix_to_face loads are in flight together and ONE LDS atomic per wave reserves the
-  // list slots of the whole group (a 32-row strip used to serialise 28 dependent load -> ballot -> atomic round trips)
-  for (int g0 = 0; g0 < n_pix; g0 += 8 * MVR_BLOCK) {
-    int fk[8];
+  // ---- compact the covered pixels of the strip (coverage ~40 %): the gradient arithmetic below then runs dense.
+  // Groups of 8 x 256 pixels (the 8 pix_to_face loads of a group are in flight together).  The list order is FIXED
+  // (group, wave, round, lane) so that the float sums below are bit-reproducible from run to run: a first sweep
+  // counts the covered pixels per (group, wave), one wave turns the counts into offsets, a second sweep (its loads
+  // hit the cache) writes the list.  Chunks of MVR_BWD_SCAN_GROUPS groups bound the offset table.
+  const int n_groups = (n_pix + 8 * MVR_BLOCK - 1) / (8 * MVR_BLOCK);
+  int chunk_base = 0;
+  for (int c0 = 0; c0 < n_groups; c0 += MVR_BWD_SCAN_GROUPS) {
+    const int c1 = min(n_groups, c0 + MVR_BWD_SCAN_GROUPS);
+    for (int gi = c0; gi < c1; ++gi) {
+      const int g0 = gi * 8 * MVR_BLOCK;
+      int total = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int pix = g0 + k * MVR_BLOCK + tid;
-      fk[k] = pix < n_pix ? p2f[pix] : -1;
+      for (int k = 0; k < 8; ++k) {
+        const int pix = g0 + k * MVR_BLOCK + tid;
+        total += __popcll(__ballot(pix < n_pix && p2f[pix] >= 0));
+      }
+      if (lane == 0) s_goff[(gi - c0) * MVR_WAVES + wave] = total;
     }
-    int cntk[8], total = 0;
+    __syncthreads();
+    if (wave == 0) {   // exclusive prefix over the (group, wave) counts of the chunk; the last slot receives the chunk total
+      const int n_ent = (c1 - c0) * MVR_WAVES;
+      const int v = lane < n_ent ? s_goff[lane] : 0;
+      int incl = v;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const bool covered = fk[k] >= 0;
-      const unsigned long long mc = __ballot(covered);
-      cntk[k] = __popcll(mc);
-      total += cntk[k];
-      fk[k] = covered ? __popcll(mc & ((1ull << lane) - 1ull)) : -1;   // rank among the round's covered lanes
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      if (lane < n_ent) s_goff[lane] = incl - v;
+      if (lane == 63) s_goff[MVR_BWD_SCAN_GROUPS * MVR_WAVES] = incl;
     }
-    int bs = 0;
-    if (lane == 0 && total) bs = atomicAdd(&s_cnt, total);
-    bs = __shfl(bs, 0);
+    __syncthreads();
+    for (int gi = c0; gi < c1; ++gi) {
+      const int g0 = gi * 8 * MVR_BLOCK;
+      int bs = chunk_base + s_goff[(gi - c0) * MVR_WAVES + wave];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (fk[k] >= 0) plist[bs + fk[k]] = g0 + k * MVR_BLOCK + tid;
-      bs += cntk[k];
+      for (int k = 0; k < 8; ++k) {
+        const int pix = g0 + k * MVR_BLOCK + tid;
+        const bool covered = pix < n_pix && p2f[pix] >= 0;
+        const unsigned long long mc = __ballot(covered);
+        if (covered) plist[bs + __popcll(mc & ((1ull << lane) - 1ull))] = pix;
+        bs += __popcll(mc);
+      }
     }
+    chunk_base += s_goff[MVR_BWD_SCAN_GROUPS * MVR_WAVES];
+    __syncthreads();
   }
-  __syncthreads();
-  const int n_cov = s_cnt;
+  const int n_cov = chunk_base;
 
   mvr::PixelGradIn<float> cam;
 #pragma unroll
@@ -1529,8 +1547,8 @@ __global__ void __launch_bounds__(MVR_BLOCK, MVR_BWD_WAVES_PER_SIMD) k_mesh_back
     const float py = -1.0f + mvr::div_by(2.0f * (float)(H - 1 - (r0 + row)) + 1.0f, fH, invH);
     mvr::phong_pixel_bwd<float>(cam, px, py, X0, X1, X2, N0, N1, N2, c0, c1, c2, G, acc);
   }
-  // wave reduce (64 lanes), then 4 waves through LDS in a fixed order.  (The order in which pixels were
-  // compacted varies from run to run, so the float sums are reproducible only to rounding.)
+  // wave reduce (64 lanes), then 4 waves through LDS in a fixed order: with the fixed list order above the
+  // partial sums — and therefore the gradients — are bit-reproducible
 #pragma unroll
   for (int k = 0; k < MVR_NACC; ++k) {
     float x = acc[k];

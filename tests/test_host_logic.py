@@ -287,3 +287,45 @@ def test_non_square_images_are_rejected_without_gpu():
     mp = _lib.MeshParams(1, 8, 9, 0, 1, 0, 60.0, 0.5, 0.3, 0.2, 64.0)
     assert lib.mvr_render_meshes_forward(mb, mp, dummy, dummy, dummy, dummy, None, dummy, 1 << 20, None) == 4
     assert b"non-square" in lib.mvr_last_error()
+
+
+def test_regularization_draws_follow_the_reference_order():
+    """mvtn_amd.regularize.draw_regularization: same generator calls, in the same order, as ops.py:168-176 +
+    util.py:193,224-231; per-image draws re-ordered from the reference's view-major flattening (m = v*B + b,
+    super_batched_op dim=1) to memory order n = b*V + v."""
+    from mvtn_amd import regularize as rg
+    assert rg.crop_padding(224, 0.3) == 67 and rg.crop_padding(224, 0.0) == 0 and rg.crop_padding(128, 0.3) == 38
+    B, V, H = 3, 4, 224
+    torch.manual_seed(11)
+    scale, flip, ci, cj, pad = rg.draw_regularization(B, V, H, torch.device("cpu"), dropout_p=0.4, augment_training=True, crop_ratio=0.3)
+    torch.manual_seed(11)
+    keep = torch.nn.functional.dropout3d(torch.ones(B, V, 1, 1, 1), p=0.4, training=True).reshape(-1)   # same mask shape, no 5-D warning
+    flipped = torch.rand(B * V) < 0.5
+    i = torch.randint(0, 2 * 67 + 1, (B * V,))
+    j = torch.randint(0, 2 * 67 + 1, (B * V,))
+    assert pad == 67 and torch.equal(scale, keep) and set(scale.tolist()) <= {0.0, float(torch.tensor(1.0) / torch.tensor(0.6))}
+    x = torch.arange(B * V).reshape(B, V, 1, 1, 1).float()
+    m_of_n = batch_tensor(x, dim=1, squeeze=True).reshape(-1).long()      # image m of the flattened batch holds memory image m_of_n[m]
+    assert torch.equal(flip[m_of_n].bool(), flipped) and torch.equal(ci[m_of_n].long(), i) and torch.equal(cj[m_of_n].long(), j)
+    assert flip.dtype == torch.uint8 and ci.dtype == torch.int32
+    assert rg.draw_regularization(B, V, H, torch.device("cpu")) == (None, None, None, None, 0)
+    img = torch.zeros(B, V, 3, 8, 8)
+    assert rg.regualarize_rendered_views(img) is img            # defaults (config.yaml:42-43): identity, as in the reference
+    with pytest.raises(ValueError):
+        rg.regualarize_rendered_views(torch.zeros(2, 3, 8, 8))
+    with pytest.raises(RuntimeError):                          # no CPU fallback
+        rg.regualarize_rendered_views(img, dropout_p=0.5)
+
+
+def test_regularize_c_abi_argument_validation_without_gpu():
+    from mvtn_amd import _lib
+    lib = _lib.load()
+    buf = (ctypes.c_float * 16)()
+    out = (ctypes.c_float * 16)()
+    a, o = ctypes.addressof(buf), ctypes.addressof(out)
+    assert lib.mvr_regularize_views_forward(None, 1, 1, 4, 4, None, None, None, None, 0, o, None) == 1
+    assert lib.mvr_regularize_views_forward(a, 1, 1, 4, 4, None, None, None, None, 0, a, None) == 1          # in place
+    assert lib.mvr_regularize_views_forward(a, 0, 1, 4, 4, None, None, None, None, 0, o, None) == 1
+    assert lib.mvr_regularize_views_forward(a, 1, 1, 4, 4, None, None, a, None, 1, o, None) == 1            # crop_i without crop_j
+    assert lib.mvr_regularize_views_backward(a, 1, 1, 4, 4, None, None, None, None, -1, o, None) == 1
+    assert b"mvr_regularize_views" in lib.mvr_last_error()
