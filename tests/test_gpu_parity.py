@@ -766,3 +766,90 @@ def test_regularize_views_after_the_renderer_trains_end_to_end():
         assert torch.equal(a, b.grad)
     dropped = (draws[0] == 0).reshape(B, V)
     assert dropped.any() and (out[dropped] == 0).all() and (got[0][dropped] == 0).all()
+
+
+# ---- SURVEY section 8c known answers, straight through the HIP library: closed-form expectations, no oracle in the loop ----
+
+def _hip_render_mesh(v, f, az, el, di, size, light=(0.0, 1.0, 0.0), obj=(1, 1, 1), bg=(0, 0, 0), persp=True):
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(np.asarray(v, np.float32))], [torch.from_numpy(np.asarray(f, np.int64))]), _dev())
+    R, T = F.look_at_view_transform(_t([di]), _t([el]), _t([az]))
+    params = F.mesh_params(1, size, 1, obj, bg, perspective_correct=persp)
+    img, p2f = F.render_meshes_fragments(packed, R, T, _t([list(light)]), params)
+    return img[0, 0].cpu().numpy(), p2f[0].cpu().numpy()
+
+
+def _tris(tris):
+    verts = np.asarray(tris, np.float32).reshape(-1, 3)
+    return verts, np.arange(len(verts)).reshape(-1, 3).astype(np.int64)
+
+
+def test_known_answers_mesh_hip():
+    s = 1.0 / np.tan(np.radians(30.0))
+    # KA2: unit sphere at d = 2.2 -> disc of NDC radius 1/(tan30 sqrt(d^2 - 1)) = 0.88388 -> 61.36 % of the pixels
+    v, f = syn.icosphere(5)
+    _, p2f = _hip_render_mesh(v, f, 30.0, 20.0, 2.2, 224)
+    assert abs((p2f >= 0).mean() - np.pi * 0.88388 ** 2 / 4) < 0.004
+    # KA3: lattice-aligned fronto-parallel right triangle: exactly the pixel centres with all barycentrics > 0
+    S, d = 16, 2.0
+    ndc = np.array([[-0.75, -0.75], [0.75, -0.75], [-0.75, 0.75]])
+    world = np.stack([-ndc[:, 0] * d / s, ndc[:, 1] * d / s, np.zeros(3)], 1)
+    _, p2f = _hip_render_mesh(*_tris([world]), 0.0, 0.0, d, S, persp=False)
+    c = -1 + (2 * np.arange(S) + 1) / S
+    X, Y = np.meshgrid(c[::-1], c[::-1])           # output (row i, col j) <-> (x, y) = (c[S-1-j], c[S-1-i])
+    assert np.array_equal(p2f >= 0, (X > -0.75) & (Y > -0.75) & (X + Y < 0.0))
+    # KA4: coincident faces -> the lower index wins; a nearer face beats a lower index
+    tri = [[-0.5, -0.5, 0.0], [0.5, -0.5, 0.0], [0.0, 0.6, 0.0]]
+    near = [[-0.5, -0.5, 0.3], [0.5, -0.5, 0.3], [0.0, 0.6, 0.3]]
+    assert set(np.unique(_hip_render_mesh(*_tris([tri, tri, tri]), 0.0, 0.0, 2.2, 32)[1])) == {-1, 0}
+    assert set(np.unique(_hip_render_mesh(*_tris([tri, near]), 0.0, 0.0, 2.2, 32)[1])) == {-1, 1}
+    # KA5 + KA6: constant-normal plane, closed-form Phong; background pixels carry the background colour exactly
+    quad_v = np.asarray([[-2, -2, 0], [2, -2, 0], [2, 2, 0], [-2, 2, 0]], np.float32)
+    quad_f = np.asarray([[0, 1, 2], [0, 2, 3]], np.int64)
+    col = 0.99999
+    cen = -1 + (2 * np.arange(8) + 1) / 8
+    for light, cosang in (((0.0, 1.0, 0.0), 0.0), ((0.0, 0.0, 1.0), 1.0), ((0.0, 1.0, 1.0), np.sqrt(0.5))):
+        img, p2f = _hip_render_mesh(quad_v, quad_f, 0.0, 0.0, 2.2, 8, light=light, obj=(col,) * 3, bg=(0.25, 0.5, 0.75))
+        assert (p2f >= 0).mean() > 0.8
+        checked = 0
+        for i in range(8):
+            for j in range(8):
+                if p2f[i, j] < 0:
+                    assert tuple(img[:, i, j]) == (0.25, 0.5, 0.75)
+                    continue
+                p = np.array([-cen[7 - j] * 2.2 / s, cen[7 - i] * 2.2 / s, 0.0])
+                vh = np.array([0, 0, 2.2]) - p
+                vh /= np.linalg.norm(vh)
+                l = np.asarray(light, float) / np.linalg.norm(light)
+                r = -l + 2 * cosang * np.array([0, 0, 1.0])
+                alpha = max(0.0, float(vh @ r)) * (1.0 if cosang > 0 else 0.0)
+                want = (0.5 + 0.3 * max(0.0, cosang)) * col + 0.2 * alpha ** 64
+                assert np.abs(img[:, i, j] - want).max() < 2e-5, (light, i, j)
+                checked += 1
+        assert checked > 50
+
+
+def test_known_answers_points_hip(oracle):
+    """KA7 through the HIP path: r = 0.006 is smaller than the pixel half-diagonal at 224^2, so a point on a pixel
+    corner hits nothing and a point on a pixel centre exactly that pixel; nearer wins, ties go to the smaller index.
+    (The oracle is used only for the look-at matrices that place the points.)"""
+    from mvtn_amd import functional as F
+    S, d = 224, 1.0
+    R64, T64 = oracle.look_at([0.0], [0.0], [d], np.float64)
+
+    def world_of(x, y, z=1.0):
+        return ((np.array([x, y, z]) - T64[0]) @ R64[0].T) * d
+
+    def render(pts, size, radius, K=1):
+        R, T = F.look_at_view_transform(_t([d]), _t([0.0]), _t([0.0]))
+        params = F.points_params(1, len(pts), 1, size, radius, (1, 0, 0), (0, 0, 0), points_per_pixel=K)
+        img, idx = F.render_points_fragments(_t(np.asarray([pts], np.float32)), None, R, T, _t([d]), params)
+        return img[0, 0].cpu().numpy(), idx[0].cpu().numpy()
+    img, idx = render([world_of(0.0, 0.0)], S, 0.006)
+    assert (idx < 0).all() and (img == 0).all()
+    img, idx = render([world_of(-1 + (2 * 100 + 1) / S, -1 + (2 * 50 + 1) / S)], S, 0.006)
+    assert np.argwhere(idx >= 0).tolist() == [[S - 1 - 50, S - 1 - 100]]
+    assert np.allclose(img[:, S - 1 - 50, S - 1 - 100], [1, 0, 0], atol=1e-6)
+    _, idx = render([world_of(0.1, 0.1, 1.5), world_of(0.1, 0.1, 0.7), world_of(0.1, 0.1, 0.7)], 64, 0.05)
+    assert set(np.unique(idx)) == {-1, 1}
