@@ -853,3 +853,49 @@ def test_known_answers_points_hip(oracle):
     assert np.allclose(img[:, S - 1 - 50, S - 1 - 100], [1, 0, 0], atol=1e-6)
     _, idx = render([world_of(0.1, 0.1, 1.5), world_of(0.1, 0.1, 0.7), world_of(0.1, 0.1, 0.7)], 64, 0.05)
     assert set(np.unique(idx)) == {-1, 1}
+
+
+@pytest.mark.parametrize("rotation_check", ["off", "device"])
+def test_training_step_is_capturable_in_a_hip_graph(rotation_check):
+    """Render + backward issue no host synchronisation and allocate only through torch's caching allocator, so a whole
+    step (forward, regulariser, loss, backward) can be captured in a HIP graph (torch.cuda.CUDAGraph) and replayed
+    with new view parameters written into the captured input tensors: replays equal eager execution bit for bit."""
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes, regularize as rg
+    dev = _dev()
+    vl, fl = _mesh_batch([("S", 0), ("M", 1)])
+    B, V, size = 2, 4, 64
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), dev)
+    r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="relative",
+                   rotation_check=rotation_check).eval()
+    G = torch.randn(B, V, 3, size, size, generator=torch.Generator().manual_seed(4)).to(dev)
+    draws = rg.draw_regularization(B, V, size, dev, 0.3, True, 0.3)
+    sets = [tuple(_t(x) for x in _views(B, 4, seed)) for seed in (1, 2, 3)]
+
+    def step(a, e, d):
+        img, _ = r(packed, None, a, e, d)
+        out = rg.apply_regularization(img, *draws)
+        return out, torch.autograd.grad((out * G).sum(), (a, e, d))
+
+    eager = []
+    for a, e, d in sets:
+        leaves = [x.clone().requires_grad_(True) for x in (a, e, d)]
+        out, grads = step(*leaves)
+        eager.append((out.detach().clone(), [g.clone() for g in grads]))
+    sa, se, sd = (x.clone().requires_grad_(True) for x in sets[0])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):                          # warm-up outside the capture (workspace sizes, caches)
+            step(sa, se, sd)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_out, g_grads = step(sa, se, sd)
+    for (a, e, d), (want_out, want_grads) in zip(sets, eager):
+        with torch.no_grad():
+            sa.copy_(a); se.copy_(e); sd.copy_(d)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g_out, want_out)
+        for got, want in zip(g_grads, want_grads):
+            assert torch.equal(got, want)
