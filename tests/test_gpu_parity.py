@@ -899,3 +899,42 @@ def test_training_step_is_capturable_in_a_hip_graph(rotation_check):
         assert torch.equal(g_out, want_out)
         for got, want in zip(g_grads, want_grads):
             assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_random_configurations_slice(oracle, seed):
+    """A seeded slice of tests/stress_parity.py inside the suite: random anisotropically scaled / shifted meshes,
+    views anywhere on the sphere, cameras from inside the bounding sphere (dist 0.9: vertices behind the camera,
+    faces crossing z = 0, NDC coordinates far outside the screen) to 3.0, odd image sizes and strip heights, both
+    PyTorch3D switch settings.  Pixel->face maps bit-exact; colours within TOL_PIXEL on well-conditioned pixels."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    rng = np.random.default_rng(seed)
+    for case in range(4):
+        B, V = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        size = int(rng.choice([32, 45, 64, 100, 128]))
+        strip = int(rng.choice([0, 0, 3, 5, 8]))
+        persp, cull = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
+        vl, fl = [], []
+        for b in range(B):
+            v, f = syn.cad_soup(int(rng.integers(0, 1000))) if rng.integers(0, 4) == 0 else \
+                syn.synthetic_mesh(str(rng.choice(["S", "M"])), int(rng.integers(0, 1000)))
+            vl.append((v * rng.uniform(0.5, 1.3, 3) + rng.uniform(-0.2, 0.2, 3)).astype(np.float32))
+            fl.append(f)
+        az = rng.uniform(-180, 180, (B, V)).astype(np.float32)
+        el = rng.uniform(-80, 80, (B, V)).astype(np.float32)
+        di = rng.uniform(0.9, 3.0, (B, V)).astype(np.float32)
+        if case == 0:
+            di[:] = 0.9                      # always include the camera-inside-the-object case
+        obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
+        want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, perspective_correct=persp,
+                                    cull_backfaces=cull, mode=1)
+        packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+        R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+        params = F.mesh_params(V, size, 1, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip)
+        img, p2f = F.render_meshes_fragments(packed, R, T, _t([[0, 1, 0]]), params)
+        p2f, img = p2f.cpu().numpy(), img.cpu().numpy()
+        assert np.array_equal(p2f, want["pix_to_face"]), (seed, case, int((p2f != want["pix_to_face"]).sum()))
+        well = _well_conditioned_pixels(vl, fl, want["pix_to_face"], V)
+        diff = np.abs(img - want["images"]).reshape(B * V, 3, size, size).max(1)
+        assert float(diff[well].max()) <= TOL_PIXEL, (seed, case, float(diff[well].max()))
