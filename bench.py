@@ -262,6 +262,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         gather = {"views_per_s_with_allgather": n_views_total * reps / float(t.item()),
                   "bytes_gathered_per_rank": int(img.numel() * 4 * world)}
+        if args.workload != "mesh_fwdbwd" and not args.host_meshes:
+            # the same exchange hidden behind the rendering: the shard is rendered in 2 pieces, piece c travels (direct
+            # sends to every peer, landing in place) while piece c+1 renders (mvtn_amd.distributed.render_sharded_overlapped)
+            from mvtn_amd.distributed import _chunk_bounds, render_sharded_overlapped, shard_range
+            chunks = 2
+            lo, hi = shard_range(B * world, world, rank)
+            azg, elg, dg = (x.detach().repeat(world, 1) for x in (azim, elev, dist_t))
+            pieces = ptsg = None
+            if args.workload == "points_fwd":
+                ptsg = torch.zeros(B * world, P, 3, device=dev)
+                ptsg[lo:hi] = points
+            else:
+                pieces = [PackedMeshes.from_meshes(Meshes(vl[a - lo:b - lo], fl[a - lo:b - lo]), dev) for a, b in _chunk_bounds(lo, hi, chunks)]
+
+            def overlapped():
+                return render_sharded_overlapped(renderer, None, ptsg, azg, elg, dg, chunks=chunks, packed_pieces=pieces)[0]
+            for _ in range(3):
+                overlapped()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                overlapped()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gather["views_per_s_with_overlapped_exchange"] = n_views_total * reps / float(t.item())
+            gather["exchange_pieces"] = chunks
 
     cpu = None
     parity = None
@@ -303,6 +330,10 @@ def main():
         if gather:
             line["allgather"] = gather
         sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)   # C stdio of the libraries (the RCCL banner is buffered there): out to stderr now
+        except OSError:
+            pass
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)

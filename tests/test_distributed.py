@@ -70,6 +70,13 @@ def _worker(rank, world, port, B, q):
         x = torch.full((2, 3), float(rank))
         y = all_gather_views(x)
         assert y.shape == (2 * world, 3) and all(float(y[2 * k, 0]) == k for k in range(world))
+        # overlapped, direct-placement exchange: same result as the unsharded render for any piece count,
+        # including pieces (and whole ranks' pieces) that are empty
+        from mvtn_amd.distributed import render_sharded_overlapped
+        for chunks in (1, 2, 3):
+            ov, cams = render_sharded_overlapped(r, None, points, azim.detach(), elev.detach(), dist_, chunks=chunks)
+            assert ov.shape == full.shape and torch.equal(ov, full.detach()), "overlapped exchange differs (chunks=%d)" % chunks
+            assert not ov.requires_grad
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, "FAIL: %r" % (e,)))
@@ -77,7 +84,7 @@ def _worker(rank, world, port, B, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [4, 5])
+@pytest.mark.parametrize("B", [4, 5, 1])
 def test_sharded_render_and_allgather_world2(B):
     world = 2
     ctx = mp.get_context("spawn")
