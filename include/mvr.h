@@ -237,6 +237,17 @@ int mvr_render_points_forward(const mvr_points_params *params, const float *poin
                               const float *dist, float *images, int32_t *pix_to_point,
                               void *workspace, size_t workspace_bytes, mvr_stream_t stream);
 
+/* The forward of the point path as ONE call (the look-at of models/renderer.py:122-125 runs inside the projection
+ * pre-pass: two launches instead of three).  azim / elev / dist: (N) degrees; max_trials / seed, azim_used /
+ * elev_used / view_valid / status: as mvr_look_at_checked; R (N,9), T (N,3) are OUTPUTS.  At most 2048 views per call
+ * (MVR_ERR_UNSUPPORTED beyond: use mvr_look_at_checked + mvr_render_points_forward).  Everything else as
+ * mvr_render_points_forward. */
+int mvr_render_point_views_forward(const mvr_points_params *params, const float *points, const float *point_colors,
+                                   const float *azim, const float *elev, const float *dist, int32_t max_trials,
+                                   uint64_t seed, float *R, float *T, float *azim_used, float *elev_used,
+                                   int32_t *view_valid, int32_t *status, float *images, int32_t *pix_to_point,
+                                   void *workspace, size_t workspace_bytes, mvr_stream_t stream);
+
 /* backward w.r.t. cameras and dist.  The compositor's weight gradient is PyTorch3D's
  * (f_k S - sum_j w_j f_j) / S^2 with S = max(sum_j w_j, 1e-4): with points_per_pixel = 1 it is exactly
  * zero except where the clamp is active.  pix_to_point is the forward's (N,H,W,K). */

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "mvr_render_meshes_backward": (ctypes.c_int, [_MB, _MP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "mvr_points_workspace_bytes": (ctypes.c_size_t, [_PP]),
     "mvr_render_points_forward": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "mvr_render_point_views_forward": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp, _vp, ctypes.c_int32, ctypes.c_uint64] + [_vp] * 9 +
+                                       [ctypes.c_size_t, _vp]),
     "mvr_render_points_backward": (ctypes.c_int, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
 }
 

@@ -479,6 +479,61 @@ struct LookAtFuse {
   int N;
 };
 
+// The look-at of a whole batch of views evaluated by ONE workgroup of MVR_PB_BLOCK threads (every view workgroup of a
+// fused pre-pass runs it: the remedy of ops.py:156-165 re-draws ALL views when any is invalid, so each workgroup needs
+// the global verdict, and 512 views per pass cost no more than one).  Publishes view n's R, T in s_RT (and in la.R /
+// la.T, with the angles used, the validity flag and, on the first trial, the camera position); a workgroup that owns
+// n_own consecutive views gets them at s_RT + 12 k.
+__device__ __forceinline__ void look_at_views_block(const LookAtFuse &la, int n, float *s_RT, int *s_bad_p, int n_own = 1) {
+  int &s_bad = *s_bad_p;
+  for (int trial = 0;; ++trial) {
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    int bad = 0;
+    // TWO lanes per view: the f64 sin/cos of the elevation (even lane) and of the azimuth (odd lane) are the long
+    // dependency chains of a look-at; side by side they take half the time.  The even lane finishes the view.
+    for (int base = 0; base < la.N; base += MVR_PB_BLOCK / 2) {
+      const int i = base + ((int)threadIdx.x >> 1);
+      const bool live = i < la.N, role_az = (threadIdx.x & 1) != 0;
+      float a = live ? la.azim[i] : 0.f, e = live ? la.elev[i] : 0.f;
+      if (trial > 0) {
+        a = a + 180.0f * rng_uniform(la.seed, trial, i, 0);
+        e = e + 90.0f * rng_uniform(la.seed, trial, i, 1);
+      }
+      float sn, cs;
+      mvr::sincos_deg<float>(role_az ? a : e, &sn, &cs);
+      const float sa = __shfl_xor(sn, 1), ca = __shfl_xor(cs, 1);   // even lanes receive the azimuth's pair
+      if (!live || role_az) continue;
+      float Ri[9], Ti[3];
+      mvr::look_at_from_position<float>(mvr::camera_position_sc<float>(sn, cs, sa, ca, la.dist[i]), Ri, Ti);
+      const bool ok = mvr::rotation_valid<float>(Ri, 1e-6f);
+      bad += ok ? 0 : 1;
+      if (i >= n && i < n + n_own) {   // this workgroup's view(s): publish (the last trial's values stay)
+        float *rt = s_RT + 12 * (i - n);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { rt[k] = Ri[k]; la.R[9 * (size_t)i + k] = Ri[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rt[9 + k] = Ti[k]; la.T[3 * (size_t)i + k] = Ti[k]; }
+        if (la.azim_used) la.azim_used[i] = a;
+        if (la.elev_used) la.elev_used[i] = e;
+        if (la.view_valid) la.view_valid[i] = ok ? 1 : 0;
+        if (trial == 0 && la.cam_pos) {   // relative light: camera position of the REQUESTED angles (= this trial's)
+          const f3 c = mvr::camera_position_sc<float>(sn, cs, sa, ca, la.dist[i]);
+          la.cam_pos[3 * i] = c.x; la.cam_pos[3 * i + 1] = c.y; la.cam_pos[3 * i + 2] = c.z;
+        }
+      }
+    }
+    if (bad) atomicAdd(&s_bad, bad);
+    __syncthreads();
+    const int nb = s_bad;
+    __syncthreads();
+    if (nb == 0 || la.max_trials < 0 || trial > la.max_trials) {
+      if (n == 0 && threadIdx.x == 0 && la.status) { la.status[0] = trial; la.status[1] = nb; }
+      break;
+    }
+  }
+}
+
 __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n, unsigned char *smem, int V, int H, int W, int G,
                                                        int stride, int cull_backfaces, const float *__restrict__ R,
                                                        const float *__restrict__ T, float s, float4 *__restrict__ proj_all,
@@ -497,51 +552,7 @@ __device__ __forceinline__ void project_bins_view_body(const MeshPtrs &m, int n,
   const int fo = m.face_off[b], nf = m.face_off[b + 1] - fo;
   float Rm[9], Tv[3];
   if (la.azim) {
-    for (int trial = 0;; ++trial) {
-      if (threadIdx.x == 0) s_bad = 0;
-      __syncthreads();
-      int bad = 0;
-      // TWO lanes per view: the f64 sin/cos of the elevation (even lane) and of the azimuth (odd lane) are the long
-      // dependency chains of a look-at; side by side they take half the time.  The even lane finishes the view.
-      for (int base = 0; base < la.N; base += MVR_PB_BLOCK / 2) {
-        const int i = base + ((int)threadIdx.x >> 1);
-        const bool live = i < la.N, role_az = (threadIdx.x & 1) != 0;
-        float a = live ? la.azim[i] : 0.f, e = live ? la.elev[i] : 0.f;
-        if (trial > 0) {
-          a = a + 180.0f * rng_uniform(la.seed, trial, i, 0);
-          e = e + 90.0f * rng_uniform(la.seed, trial, i, 1);
-        }
-        float sn, cs;
-        mvr::sincos_deg<float>(role_az ? a : e, &sn, &cs);
-        const float sa = __shfl_xor(sn, 1), ca = __shfl_xor(cs, 1);   // even lanes receive the azimuth's pair
-        if (!live || role_az) continue;
-        float Ri[9], Ti[3];
-        mvr::look_at_from_position<float>(mvr::camera_position_sc<float>(sn, cs, sa, ca, la.dist[i]), Ri, Ti);
-        const bool ok = mvr::rotation_valid<float>(Ri, 1e-6f);
-        bad += ok ? 0 : 1;
-        if (i == n) {   // this workgroup's view: publish (the last trial's values stay)
-#pragma unroll
-          for (int k = 0; k < 9; ++k) { s_RT[k] = Ri[k]; la.R[9 * (size_t)n + k] = Ri[k]; }
-#pragma unroll
-          for (int k = 0; k < 3; ++k) { s_RT[9 + k] = Ti[k]; la.T[3 * (size_t)n + k] = Ti[k]; }
-          if (la.azim_used) la.azim_used[n] = a;
-          if (la.elev_used) la.elev_used[n] = e;
-          if (la.view_valid) la.view_valid[n] = ok ? 1 : 0;
-          if (trial == 0 && la.cam_pos) {   // relative light: camera position of the REQUESTED angles (= this trial's)
-            const f3 c = mvr::camera_position_sc<float>(sn, cs, sa, ca, la.dist[n]);
-            la.cam_pos[3 * n] = c.x; la.cam_pos[3 * n + 1] = c.y; la.cam_pos[3 * n + 2] = c.z;
-          }
-        }
-      }
-      if (bad) atomicAdd(&s_bad, bad);
-      __syncthreads();
-      const int nb = s_bad;
-      __syncthreads();
-      if (nb == 0 || la.max_trials < 0 || trial > la.max_trials) {
-        if (n == 0 && threadIdx.x == 0 && la.status) { la.status[0] = trial; la.status[1] = nb; }
-        break;
-      }
-    }
+    look_at_views_block(la, n, s_RT, &s_bad);
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rm[k] = s_RT[k];
 #pragma unroll
@@ -1730,6 +1741,45 @@ __global__ void __launch_bounds__(MVR_BLOCK) k_points_project(PointsArgs a, floa
   }
 }
 
+// Look-at + projection in one launch (MVR_PB_BLOCK threads per workgroup): the forward of the point path then is two
+// launches (this + the rasteriser) instead of three.  A 1024-thread workgroup with the look-at's f64 chains fills a
+// CU, so every workgroup takes `vpw` consecutive views such that all workgroups are resident at once (256 CUs).
+#define MVR_POINTS_PREPASS_MAX_VPW 8
+__global__ void __launch_bounds__(MVR_PB_BLOCK) k_points_prepass(PointsArgs a, LookAtFuse la, int vpw, float4 *__restrict__ pv,
+                                                                unsigned short *__restrict__ pbin) {
+  __shared__ float s_RT[12 * MVR_POINTS_PREPASS_MAX_VPW];
+  __shared__ int s_bad;
+  const int n0 = blockIdx.x * vpw, n_own = min(vpw, a.N - n0);
+  look_at_views_block(la, n0, s_RT, &s_bad, n_own);
+  const float rG = __builtin_amdgcn_rcpf((float)a.bin_rows);
+  for (int k = 0; k < n_own; ++k) {
+    const int n = n0 + k, b = n / a.V;
+    float Rm[9], Tv[3];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) Rm[j] = s_RT[12 * k + j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Tv[j] = s_RT[12 * k + 9 + j];
+    const float sc = 1.0f / a.dist[n];
+    for (int p = threadIdx.x; p < a.P; p += MVR_PB_BLOCK) {   // same arithmetic as k_points_project
+      const f3 q = point_view(Rm, Tv, sc, a.points + 3 * ((size_t)b * a.P + p));
+      unsigned short out = MVR_BIN_NONE;
+      if (q.z >= 0.0f && q.x - a.radius <= 1.0f && q.x + a.radius >= -1.0f && q.y - a.radius <= 1.0f && q.y + a.radius >= -1.0f) {
+        int y0, y1;
+        ndc_range(q.y - a.radius, q.y + a.radius, a.H, &y0, &y1);
+        if (y0 <= y1) {
+          const int r0 = a.H - 1 - y1, r1 = a.H - 1 - y0;
+          int g0 = (int)((float)r0 * rG), g1 = (int)((float)r1 * rG);
+          g0 += (r0 - g0 * a.bin_rows >= a.bin_rows ? 1 : 0) - (r0 - g0 * a.bin_rows < 0 ? 1 : 0);
+          g1 += (r1 - g1 * a.bin_rows >= a.bin_rows ? 1 : 0) - (r1 - g1 * a.bin_rows < 0 ? 1 : 0);
+          out = (unsigned short)(g0 | (g1 << 8));
+        }
+      }
+      pv[(size_t)n * a.pstride + p] = make_float4(q.x, q.y, q.z, 0.f);
+      pbin[(size_t)n * a.pstride + p] = out;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(MVR_BLOCK) k_points_raster_shade(PointsArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int W = a.W, H = a.H, TH = a.TH;
@@ -2536,9 +2586,10 @@ static int check_points_args(const mvr_points_params *p) {
   return MVR_OK;
 }
 
-int mvr_render_points_forward(const mvr_points_params *p, const float *points, const float *point_colors, const float *R,
-                              const float *T, const float *dist, float *images, int32_t *pix_to_point, void *workspace,
-                              size_t workspace_bytes, mvr_stream_t stream) {
+#define MVR_POINT_VIEWS_FUSED_MAX 2048
+static int points_forward_impl(const mvr_points_params *p, const float *points, const float *point_colors, const float *R,
+                               const float *T, const float *dist, float *images, int32_t *pix_to_point, void *workspace,
+                               size_t workspace_bytes, mvr_stream_t stream, const LookAtFuse *fuse) {
   int rc = check_points_args(p);
   if (rc != MVR_OK) return rc;
   if (!points || !R || !T || !dist || !images || !workspace)
@@ -2553,8 +2604,12 @@ int mvr_render_points_forward(const mvr_points_params *p, const float *points, c
   a.radius = (float)p->radius; a.r2 = a.radius * a.radius; a.r2w = (float)(p->radius * p->radius);
   for (int k = 0; k < 3; ++k) { a.obj[k] = p->obj_color[k]; a.bg[k] = p->bg_color[k]; }
   a.bin_rows = bin_rows_for(a.H, a.TH);
-  hipLaunchKernelGGL(k_points_project, dim3((a.P + 4 * MVR_BLOCK - 1) / (4 * MVR_BLOCK), a.N), dim3(MVR_BLOCK), 0, (hipStream_t)stream, a,
-                     ws.pv, ws.pbin);
+  if (fuse) {
+    const int vpw = (a.N + 255) / 256;   // <= MVR_POINTS_PREPASS_MAX_VPW (N <= MVR_POINT_VIEWS_FUSED_MAX)
+    hipLaunchKernelGGL(k_points_prepass, dim3((a.N + vpw - 1) / vpw), dim3(MVR_PB_BLOCK), 0, (hipStream_t)stream, a, *fuse, vpw, ws.pv, ws.pbin);
+  } else
+    hipLaunchKernelGGL(k_points_project, dim3((a.P + 4 * MVR_BLOCK - 1) / (4 * MVR_BLOCK), a.N), dim3(MVR_BLOCK), 0, (hipStream_t)stream, a,
+                       ws.pv, ws.pbin);
   HIP_TRY(hipGetLastError());
   const int K = points_k(p);
   const size_t list_ints = (size_t)a.TH * (a.W / 4) > MVR_PTS_LIST_INTS ? (size_t)a.TH * (a.W / 4) : MVR_PTS_LIST_INTS;   // hit list / slow-group list
@@ -2572,6 +2627,24 @@ int mvr_render_points_forward(const mvr_points_params *p, const float *points, c
       hipLaunchKernelGGL(k_points_raster_shade, dim3(grid), dim3(MVR_BLOCK), lds, (hipStream_t)stream, a);
   }
   return hip_check(hipGetLastError(), "k_points_raster_shade");
+}
+
+int mvr_render_points_forward(const mvr_points_params *p, const float *points, const float *point_colors, const float *R,
+                              const float *T, const float *dist, float *images, int32_t *pix_to_point, void *workspace,
+                              size_t workspace_bytes, mvr_stream_t stream) {
+  return points_forward_impl(p, points, point_colors, R, T, dist, images, pix_to_point, workspace, workspace_bytes, stream, nullptr);
+}
+
+int mvr_render_point_views_forward(const mvr_points_params *p, const float *points, const float *point_colors, const float *azim,
+                                   const float *elev, const float *dist, int32_t max_trials, uint64_t seed, float *R, float *T,
+                                   float *azim_used, float *elev_used, int32_t *view_valid, int32_t *status, float *images,
+                                   int32_t *pix_to_point, void *workspace, size_t workspace_bytes, mvr_stream_t stream) {
+  if (!azim || !elev || !dist || !R || !T) return set_err(MVR_ERR_INVALID_ARG, "mvr_render_point_views_forward: null pointer");
+  if (p && (long long)p->n_clouds * p->n_views > MVR_POINT_VIEWS_FUSED_MAX)   // every workgroup evaluates all views' look-at
+    return set_err(MVR_ERR_UNSUPPORTED, "mvr_render_point_views_forward: too many views for the fused look-at; use mvr_look_at_checked + mvr_render_points_forward");
+  const LookAtFuse fuse = {azim, elev, dist, (int)max_trials, (unsigned long long)seed, R, T, azim_used, elev_used,
+                           nullptr, view_valid, status, p ? p->n_clouds * p->n_views : 0};
+  return points_forward_impl(p, points, point_colors, R, T, dist, images, pix_to_point, workspace, workspace_bytes, stream, &fuse);
 }
 
 int mvr_render_points_backward(const mvr_points_params *p, const float *points, const float *point_colors, const float *R,

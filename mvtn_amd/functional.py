@@ -376,6 +376,35 @@ class _RenderPoints(torch.autograd.Function):
         return gR, gT, gD, None, None, None, None
 
 
+POINT_VIEWS_FUSED_MAX = 2048   # MVR_POINT_VIEWS_FUSED_MAX: views one fused call accepts
+
+
+def render_point_views(points, colors, azim, elev, dist, params, max_trials=-1, seed=0, host_status=None):
+    """(images (B,V,3,H,W), R (N,3,3), T (N,3), status) for flat (N,) azim / elev / dist in degrees: the forward of
+    the point path of models/renderer.py:116-151 as ONE library call (look-at inside the projection pre-pass).
+    Inference only (no autograd graph): with gradients use look_at_view_transform + render_points."""
+    lib = _lib.load()
+    azim, elev, dist = _f32c(azim.detach().reshape(-1)), _f32c(elev.detach().reshape(-1)), _f32c(dist.detach().reshape(-1))
+    _require_cuda(azim, elev, dist, points, colors)
+    B, V, H, W = params.n_clouds, params.n_views, params.image_h, params.image_w
+    N = B * V
+    if azim.numel() != N or dist.numel() != N:
+        raise ValueError("azim/elev/dist must have B*V = %d elements" % N)
+    dev = azim.device
+    R = torch.empty(N, 3, 3, dtype=torch.float32, device=dev)
+    T = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    status = torch.empty(N + 2, dtype=torch.int32, device=dev)
+    images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=dev)
+    ws_bytes = lib.mvr_points_workspace_bytes(params)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    sp = status.data_ptr() if host_status is None else host_status.data_ptr()
+    _lib.check(lib.mvr_render_point_views_forward(params, points.data_ptr(), _ptr(colors), azim.data_ptr(), elev.data_ptr(),
+                                                  dist.data_ptr(), int(max_trials), int(seed) & 0xFFFFFFFFFFFFFFFF, R.data_ptr(),
+                                                  T.data_ptr(), None, None, status[2:].data_ptr(), sp, images.data_ptr(), None,
+                                                  ws.data_ptr(), ws_bytes, _stream()), "mvr_render_point_views_forward")
+    return images, R, T, status
+
+
 def render_points(points, colors, R, T, dist, params):
     """images (B,V,3,H,W) — PointsRenderer(PointsRasterizer, NormWeightedCompositor) over the
     1/dist-scaled clouds of models/renderer.py:129-145 plus the re-layout of :146-150."""

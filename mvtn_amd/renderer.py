@@ -207,6 +207,13 @@ class MVRenderer(nn.Module):
         if azim.numel() != B * self.nb_views:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (B, self.nb_views))
         flat_dist = flatten_views(dist)
+        need_grad = torch.is_grad_enabled() and (azim.requires_grad or elev.requires_grad or dist.requires_grad)
+        if not need_grad and self.rotation_check != "sync" and B * self.nb_views <= F.POINT_VIEWS_FUSED_MAX:
+            # inference: look-at + projection + rasterisation in one library call (two launches)
+            max_trials, seed, host = self._device_remedy_args() if self.rotation_check == "device" else (-1, 0, None)
+            images, R, T, _ = F.render_point_views(pts, colors, flatten_views(azim), flatten_views(elev), flat_dist, params,
+                                                   max_trials=max_trials, seed=seed, host_status=host)
+            return images, Cameras(R, T, "orthographic", znear=0.01)
         R, T, status = self._cameras(azim, elev, dist)
         images = F.render_points(pts, colors, R, T, flat_dist, params)
         if self.rotation_check == "sync" and int(status[1].item()) != 0:

@@ -972,3 +972,41 @@ def test_mesh_backward_random_configurations(oracle, seed):
         got = leaf.grad.cpu().numpy().astype(np.float64)
         rel = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
         assert rel < 2e-3, (seed, name, rel, got, ref)
+
+
+@pytest.mark.parametrize("degenerate", [False, True])
+def test_fused_point_views_forward_equals_chained_calls(degenerate):
+    """mvr_render_point_views_forward (look-at inside the projection pre-pass) against mvr_look_at_checked +
+    mvr_render_points_forward with the same remedy seed: identical R, T, status and images — also when a view at
+    elev = 89.9999 makes the device-side remedy re-draw all views."""
+    from mvtn_amd import MVRenderer, functional as F
+    B, P, V, size = 3, 2048, 5, 128
+    rng = np.random.default_rng(8)
+    pts = _t(rng.normal(size=(B, P, 3)) * 0.35)
+    cols = _t(rng.uniform(0, 1, (B, P, 3)))
+    az = rng.uniform(-180, 180, (B, V)).astype(np.float32)
+    el = rng.uniform(-70, 70, (B, V)).astype(np.float32)
+    di = rng.uniform(0.9, 2.0, (B, V)).astype(np.float32)
+    if degenerate:
+        el[1, 2] = 89.9999      # (exactly 90 is repaired inside the look-at)
+    params = F.points_params(B, P, V, size, 0.01, (1, 1, 1), (0.2, 0.3, 0.4))
+    a, e, d = _t(az.reshape(-1)), _t(el.reshape(-1)), _t(di.reshape(-1))
+    img1, R1, T1, st1 = F.render_point_views(pts, cols, a, e, d, params, max_trials=20, seed=1234)
+    R2, T2, st2 = F.look_at_view_transform(d, e, a, return_status=True, max_trials=20, seed=1234)
+    img2, _ = F.render_points_fragments(pts, cols, R2, T2, d, params)
+    assert torch.equal(R1, R2) and torch.equal(T1, T2) and torch.equal(st1, st2)
+    assert torch.equal(img1, img2)
+    assert (int(st1[0]) > 0) == degenerate and int(st1[1]) == 0
+    # the module takes the fused call under no_grad and the chained autograd nodes otherwise: same images
+    r = MVRenderer(V, size, pc_rendering=True, object_color="custom", background_color="white", points_radius=0.01,
+                   rotation_check="off" if not degenerate else "device").eval()
+    ta, te, td = _t(az), _t(el), _t(di)
+    with torch.no_grad():
+        fused, cams_f = r(None, pts, ta, te, td, color=cols)
+    if not degenerate:
+        chained, cams_c = r(None, pts, ta.clone().requires_grad_(True), te, td, color=cols)
+        assert torch.equal(fused, chained.detach()) and torch.equal(cams_f.R, cams_c.R.detach()) and torch.equal(cams_f.T, cams_c.T.detach())
+    else:
+        r.check_status()        # the re-draw succeeded: no "Remedy did not work"
+        from mvtn_amd.helpers import check_valid_rotation_matrix
+        assert check_valid_rotation_matrix(cams_f.R)
