@@ -25,21 +25,31 @@ def _stale(target, sources):
 
 def _sources():
     inc = os.path.join(os.path.dirname(_HERE), "include", "mvr.h")
+    # [0] the kernel translation unit (it #includes the mvr_*.inc sections), [3] the host packer, [4] the regulariser;
+    # the rest only take part in the staleness check
+    import glob
     return [os.path.join(CSRC, "mvr_kernels.hip"), os.path.join(CSRC, "mvr_math.h"), inc, os.path.join(CSRC, "mvr_pack.cpp"),
-            os.path.join(CSRC, "mvr_regularize.hip")]
+            os.path.join(CSRC, "mvr_regularize.hip")] + sorted(glob.glob(os.path.join(CSRC, "*.inc")))
 
 
-def build_hip(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 ... -> mvtn_amd/libmvr_hip.so"""
+def build_hip(force=False, verbose=False, out=None, extra_flags=()):
+    """hipcc --offload-arch=gfx950 ... -> mvtn_amd/libmvr_hip.so.  `out` + `extra_flags` (-D switches): developer
+    variants for tools/ (ablation / diagnostic builds loaded through MVR_LIB), never the product library."""
     srcs = _sources()
+    if out is not None:
+        return _compile(srcs, out, list(extra_flags), verbose)
     if not force and not _stale(LIB_PATH, srcs):
         return LIB_PATH
+    return _compile(srcs, LIB_PATH, [], verbose)
+
+
+def _compile(srcs, LIB_PATH, extra, verbose):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     # the host-only mesh packer is plain C++: g++ builds the object (function multi-versioning for its
     # narrowing loop), hipcc links it into the one library
-    pack_o = os.path.join(CSRC, "mvr_pack.o")
+    pack_o = LIB_PATH + ".pack.o"
     cmds = [["g++", "-O3", "-std=c++17", "-fPIC", "-fvisibility-inlines-hidden", "-c", "-o", pack_o, srcs[3]],
-            [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH, srcs[0], srcs[4], "-Wl," + pack_o]]
+            [hipcc] + HIPCC_FLAGS + extra + ["-o", LIB_PATH, srcs[0], srcs[4], "-Wl," + pack_o]]
     try:
         for cmd in cmds:
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -67,4 +77,10 @@ def build_hostmath(force=False):
 
 
 if __name__ == "__main__":
-    print(build_hip(force=True, verbose=True))
+    # python mvtn_amd/build.py                      -> the product library
+    # python mvtn_amd/build.py OUT.so -DFOO -DBAR=1 -> a developer variant (see tools/)
+    import sys
+    if len(sys.argv) > 1:
+        print(build_hip(out=sys.argv[1], extra_flags=sys.argv[2:], verbose=True))
+    else:
+        print(build_hip(force=True, verbose=True))

@@ -19,8 +19,7 @@ args = ap.parse_args()
 
 diag = os.path.join(ROOT, "mvtn_amd", "libmvr_hip_diag.so")
 from mvtn_amd import build as b  # noqa: E402
-cmd = ["hipcc"] + b.HIPCC_FLAGS + ["-DMVR_DIAG"] + ([x for x in os.environ.get("MVR_DIAG_EXTRA", "").split() if x]) + ["-o", diag, os.path.join(b.CSRC, "mvr_kernels.hip")]
-subprocess.run(cmd, check=True)
+b.build_hip(out=diag, extra_flags=["-DMVR_DIAG"] + [x for x in os.environ.get("MVR_DIAG_EXTRA", "").split() if x])
 os.environ["MVR_LIB"] = diag
 
 import numpy as np  # noqa: E402

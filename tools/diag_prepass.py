@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mvtn_amd import build as b
 diag = os.path.join(ROOT, "mvtn_amd", "libmvr_hip_diag.so")
-subprocess.run(["hipcc"] + b.HIPCC_FLAGS + ["-DMVR_DIAG"] + sys.argv[1:] + ["-o", diag, os.path.join(b.CSRC, "mvr_kernels.hip")], check=True)
+b.build_hip(out=diag, extra_flags=["-DMVR_DIAG"] + sys.argv[1:])
 os.environ["MVR_LIB"] = diag
 import numpy as np, torch
 from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, synthetic as syn

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 from mvtn_amd import build as b  # noqa: E402
 
 diag = os.path.join(ROOT, "mvtn_amd", "libmvr_hip_diag.so")
-subprocess.run(["hipcc"] + b.HIPCC_FLAGS + ["-DMVR_DIAG", "-o", diag, os.path.join(b.CSRC, "mvr_kernels.hip")], check=True)
+b.build_hip(out=diag, extra_flags=["-DMVR_DIAG"])
 for pad in (0, 8 * 1024, 20 * 1024, 50 * 1024, 100 * 1024):
     env = dict(os.environ, MVR_LIB=diag, MVR_LDS_PAD=str(pad))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "50", "--warmup", "10"],

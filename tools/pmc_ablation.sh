@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for v in full NO_LOOP NO_SHADE "NO_LOOP -DMVR_ABL_NO_SHADE"; do
   d=""; [ "$v" != full ] && d="-DMVR_ABL_$v"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math $d -o /tmp/libabl.so mvtn_amd/csrc/mvr_kernels.hip
+  python3 mvtn_amd/build.py /tmp/libabl.so $d > /dev/null
   export MVR_LIB=/tmp/libabl.so
   rm -rf /tmp/pmc_abl
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_LDS --output-format csv -d /tmp/pmc_abl -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1

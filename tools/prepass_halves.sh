@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 for v in 6400 1400 700; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -DMVR_NRM_LDS_VERTS=$v -o /tmp/libpp.so mvtn_amd/csrc/mvr_kernels.hip
+  python3 mvtn_amd/build.py /tmp/libpp.so -DMVR_NRM_LDS_VERTS=$v > /dev/null
   d=/tmp/pp_prof_$v; rm -rf $d
   MVR_LIB=/tmp/libpp.so rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
   f=$(find $d -name "*kernel_stats.csv" | head -1)
