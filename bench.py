@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--rotation-check", default="device", choices=["device", "sync", "off"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--exchange-pieces", type=int, default=0,
+                    help="N>1: also time mvtn_amd.distributed.render_sharded_overlapped with this many pieces (0 = off)")
     ap.add_argument("--host-meshes", action="store_true", help="hand CPU meshes to every step (the reference's interface): packing + H2D inside the timed region; documentation only, never the headline")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (self-test of the N>1 code path)")
     ap.add_argument("--cpu-views", type=int, default=16, help="views in the cpu_baseline sample (~0.7 s each for meshes)")
@@ -262,11 +264,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         gather = {"views_per_s_with_allgather": n_views_total * reps / float(t.item()),
                   "bytes_gathered_per_rank": int(img.numel() * 4 * world)}
-        if args.workload != "mesh_fwdbwd" and not args.host_meshes:
+        if args.exchange_pieces > 0 and args.workload != "mesh_fwdbwd" and not args.host_meshes:
             # the same exchange hidden behind the rendering: the shard is rendered in 2 pieces, piece c travels (direct
             # sends to every peer, landing in place) while piece c+1 renders (mvtn_amd.distributed.render_sharded_overlapped)
             from mvtn_amd.distributed import _chunk_bounds, render_sharded_overlapped, shard_range
-            chunks = 2
+            chunks = args.exchange_pieces
             lo, hi = shard_range(B * world, world, rank)
             azg, elg, dg = (x.detach().repeat(world, 1) for x in (azim, elev, dist_t))
             pieces = ptsg = None
