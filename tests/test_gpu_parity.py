@@ -1010,3 +1010,23 @@ def test_fused_point_views_forward_equals_chained_calls(degenerate):
         r.check_status()        # the re-draw succeeded: no "Remedy did not work"
         from mvtn_amd.helpers import check_valid_rotation_matrix
         assert check_valid_rotation_matrix(cams_f.R)
+
+
+def test_render_and_save_writes_grid_and_camera_plot(tmp_path):
+    """models/renderer.py:200-207: a no-grad forward, the image grid of the first object and the camera plot."""
+    pytest.importorskip("matplotlib")
+    from mvtn_amd import MVRenderer, Meshes
+    v, f = syn.synthetic_mesh("S", 0)
+    V, size = 4, 64
+    r = MVRenderer(V, size, pc_rendering=False, light_direction="fixed").eval()
+    az, el, di = syn.circular_views(V)
+    ta, te, td = _t(az[None]).requires_grad_(True), _t(el[None]), _t(di[None])
+    img_path, cam_path = str(tmp_path / "views.png"), str(tmp_path / "cams.png")
+    r.render_and_save([Meshes([v], [f])], None, ta, te, td, img_path, cam_path)
+    for p in (img_path, cam_path):
+        data = open(p, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n" and len(data) > 500
+    import struct
+    w, h = struct.unpack(">II", open(img_path, "rb").read()[16:24])
+    assert (w, h) == (V * (size + 2) + 2, size + 4)      # one row of V views, 2-pixel padding (util.py:667-673)
+    assert ta.grad is None

@@ -61,3 +61,14 @@ def test_cameras_world_transform_inverts_the_view_transform():
     world = cams.get_world_to_view_transform().inverse().transform_points(p_cam)
     back = world @ R + T[:, None, :]
     assert torch.allclose(back, p_cam[None].expand(2, -1, -1), atol=1e-6)
+
+
+def test_save_cameras_writes_a_plot(tmp_path):
+    pytest = __import__("pytest")
+    pytest.importorskip("matplotlib")
+    R = torch.eye(3)[None].repeat(3, 1, 1)
+    T = torch.tensor([[0.0, 0, 2.2], [0.1, 0.0, 2.0], [0.0, -0.1, 1.8]])
+    path = str(tmp_path / "cams.png")
+    viz.save_cameras(Cameras(R, T, "perspective"), path, scale=0.22, dpi=50)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and len(data) > 1000
