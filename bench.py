@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--rotation-check", default="device", choices=["device", "sync", "off"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream throughput leg")
     ap.add_argument("--exchange-pieces", type=int, default=0,
                     help="N>1: also time mvtn_amd.distributed.render_sharded_overlapped with this many pieces (0 = off)")
     ap.add_argument("--host-meshes", action="store_true", help="hand CPU meshes to every step (the reference's interface): packing + H2D inside the timed region; documentation only, never the headline")
@@ -247,6 +248,29 @@ def main():
     except Exception:
         pass
 
+    # ---- beside `value`: the same K forwards issued round-robin on two streams (mvtn_amd.pipeline.StreamPipeline):
+    # independent batches in flight, the pre-pass of one fills the rasteriser tail of the other.  An inference-time
+    # usage pattern (training steps depend on each other), reported separately and never part of `value`.
+    pipelined = None
+    if args.workload == "mesh_fwd" and not args.host_meshes and not args.no_pipelined:   # (the point kernels have no tail to fill)
+        from mvtn_amd.pipeline import StreamPipeline
+        pipe = StreamPipeline(2, dev)
+        for _ in range(min(args.warmup, 50)):
+            pipe.submit(step, inputs_ready=True)
+        pipe.join()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.submit(step, inputs_ready=True)
+        pipe.join()
+        barrier()
+        tp = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([tp], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tp = float(t.item())
+        pipelined = {"streams": 2, "views_per_s": n_views_total * args.steps / tp, "ms_per_step": tp / args.steps * 1e3}
+
     # ---- optional: the all-gather of rendered views the north_star names (not part of `value`) --------
     gather = None
     if dist_on and not args.no_gather:
@@ -333,6 +357,8 @@ def main():
         }
         if gather:
             line["allgather"] = gather
+        if pipelined:
+            line["two_streams"] = pipelined
         sys.stdout.flush()
         try:
             ctypes.CDLL(None).fflush(None)   # C stdio of the libraries (the RCCL banner is buffered there): out to stderr now

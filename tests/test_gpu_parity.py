@@ -1030,3 +1030,29 @@ def test_render_and_save_writes_grid_and_camera_plot(tmp_path):
     w, h = struct.unpack(">II", open(img_path, "rb").read()[16:24])
     assert (w, h) == (V * (size + 2) + 2, size + 4)      # one row of V views, 2-pixel padding (util.py:667-673)
     assert ta.grad is None
+
+
+def test_stream_pipeline_gives_the_same_images():
+    """mvtn_amd.pipeline.StreamPipeline: independent forwards issued round-robin on two streams, then joined."""
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes
+    from mvtn_amd.pipeline import StreamPipeline
+    V, size = 6, 128
+    r = MVRenderer(V, size, pc_rendering=False, light_direction="fixed", rotation_check="off").eval()
+    jobs = []
+    for k in range(6):
+        vl, fl = _mesh_batch([("S", k), ("M", 10 + k)])
+        packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+        jobs.append((packed,) + tuple(_t(x[:, :V]) for x in _views(2, 6, 50 + k)))
+    with torch.no_grad():
+        want = [r(p, None, a, e, d)[0].clone() for p, a, e, d in jobs]
+    torch.cuda.synchronize()
+    pipe = StreamPipeline(2)
+    got = []
+    for rep in range(3):
+        got += [pipe.submit(r, p, None, a, e, d)[0] for p, a, e, d in jobs]
+    pipe.join()
+    total = torch.stack([g.sum() for g in got])     # consumed on the caller's stream after the join
+    torch.cuda.synchronize()
+    for i, g in enumerate(got):
+        assert torch.equal(g, want[i % len(jobs)]), i
+    assert torch.isfinite(total).all()
