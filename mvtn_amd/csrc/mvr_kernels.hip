@@ -3,11 +3,11 @@
 // Path: models/renderer.py MVRenderer.forward (reference :173-198) -> render_meshes (:65-114) /
 // render_points (:116-151) and their autograd backward.  Design:
 //
-//   mesh forward = 3 launches on the caller's stream
-//     k_look_at            : R, T of all views (+ validity, device-side remedy, relative-light camera positions)
+//   mesh forward = 2 launches on the caller's stream (3 through the fine-grained entry points, which run k_look_at first)
 //     k_mesh_prepass       : workgroups [0, B): world-space vertex normals once per MESH (64-bit fixed-point LDS sums);
-//                            workgroups [B, B+N): one VIEW each: project the vertices (16 B records, L2 resident), 2-byte
-//                            row-bin range per face, per-strip face lists (near faces first), per-view shading constants
+//                            workgroups [B, B+N): one VIEW each: look-at of all views (R, T, validity, device-side
+//                            remedy, relative-light camera positions), project the vertices (16 B records, L2 resident),
+//                            2-byte row-bin range per face, per-strip face lists (near faces first), shading constants
 //     k_mesh_raster_shade  : one workgroup per (view, strip of 8 rows), heaviest strips first:
 //         list -> setup (one lane per face: exact candidate range, signed coefficient record in LDS) -> balanced
 //         split of the batch's pixel PAIRS over the lanes -> packed-f32 exact inside test / barycentrics / depth ->
@@ -16,7 +16,8 @@
 //         covered pixels are compacted and shaded (Phong + hard blend), planar (B,V,3,H,W) stores.
 //     No per-pixel fragment tensors, no bin tables, no V-fold mesh copies ever touch HBM.
 //   mesh backward = k_mesh_backward (per covered pixel, 18 partial sums per workgroup) + one finalize launch
-//   points        = k_points_project + k_points_raster_shade (hits compacted, 16-byte stores) [+ k_points_raster_topk]
+//   points        = k_points_prepass (look-at + projection; k_points_project when R, T are given) + k_points_raster_shade
+//                   (hits compacted, 16-byte stores) [k_points_raster_topk for points_per_pixel > 1]
 //
 // wave = 64 lanes; block = 256 threads (4 waves); strips are full image rows so every store
 // instruction writes whole contiguous rows.
