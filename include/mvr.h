@@ -45,8 +45,10 @@ enum {
 enum {
   MVR_CULL_BACKFACES = 1,      /* RasterizationSettings(cull_backfaces=...), models/renderer.py:98 */
   MVR_PERSPECTIVE_CORRECT = 2, /* PyTorch3D >=0.5 default for perspective cameras */
-  MVR_WORKSPACE_FROM_FORWARD = 4 /* mvr_render_meshes_backward only: `workspace` is the (unmodified) buffer the
+  MVR_WORKSPACE_FROM_FORWARD = 4, /* mvr_render_meshes_backward only: `workspace` is the (unmodified) buffer the
                                     matching mvr_render_meshes_forward call used -> its vertex normals are reused */
+  MVR_RASTER_EXACT_ONLY = 8    /* forward only: skip the fast rasteriser (exact coverage + provably ordered affine inverse
+                                  depth) and run every strip through the exact-arithmetic kernel; same images, slower */
 };
 
 /* A batch of B triangle meshes packed back to back (what models/renderer.py:66-77 builds
@@ -170,6 +172,12 @@ int mvr_pack_meshes_host(const mvr_pack_layout *layout, const float *const *vert
 
 /* Scratch the mesh calls need (vertex attributes, projected vertices, backward partials). */
 size_t mvr_mesh_workspace_bytes(const mvr_mesh_batch *meshes, const mvr_mesh_params *params);
+
+/* Diagnostics: how many (view, strip) tiles of the LAST forward that used `workspace` the fast rasteriser could not
+ * decide and handed to the exact-arithmetic kernel (coincident / intersecting faces, extreme depths).  Only meaningful
+ * after a forward that ran the fast rasteriser (perspective-correct, no MVR_RASTER_EXACT_ONLY).  count: 1 device int. */
+int mvr_mesh_redo_count(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const void *workspace, size_t workspace_bytes,
+                        int32_t *count, mvr_stream_t stream);
 
 /* World-space area-weighted vertex normals (Meshes.verts_normals_packed, used by
  * HardPhongShader at :102).  normals: (total_verts, 3).  Uses `workspace` as scratch. */

@@ -13,6 +13,7 @@ MVR_OK = 0
 MVR_CULL_BACKFACES = 1
 MVR_PERSPECTIVE_CORRECT = 2
 MVR_WORKSPACE_FROM_FORWARD = 4
+MVR_RASTER_EXACT_ONLY = 8
 
 
 class MeshBatch(ctypes.Structure):  # struct mvr_mesh_batch
@@ -66,6 +67,7 @@ PROTOTYPES = {
     "mvr_camera_position": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     "mvr_camera_position_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "mvr_mesh_workspace_bytes": (ctypes.c_size_t, [_MB, _MP]),
+    "mvr_mesh_redo_count": (ctypes.c_int, [_MB, _MP, _vp, ctypes.c_size_t, _vp, _vp]),
     "mvr_vertex_normals": (ctypes.c_int, [_MB, _vp, _vp, ctypes.c_size_t, _vp]),
     "mvr_render_meshes_forward": (ctypes.c_int, [_MB, _MP, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "mvr_render_meshes_backward": (ctypes.c_int, [_MB, _MP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),

@@ -58,6 +58,9 @@ typedef V3<float> f3;
 #ifndef MVR_RB_WAVES_PER_SIMD
 #define MVR_RB_WAVES_PER_SIMD 4
 #endif
+#ifndef MVR_FAST_WAVES_PER_SIMD
+#define MVR_FAST_WAVES_PER_SIMD 4
+#endif
 #define MVR_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define MVR_NACC 18
 
@@ -108,6 +111,7 @@ struct ProfScope {
 #include "mvr_cameras.inc"
 #include "mvr_mesh_prepass.inc"
 #include "mvr_mesh_raster.inc"
+#include "mvr_mesh_raster_fast.inc"
 #include "mvr_mesh_backward.inc"
 #include "mvr_points.inc"
 #include "mvr_abi.inc"
