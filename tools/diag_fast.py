@@ -1,0 +1,46 @@
+"""Developer tool: phase times of k_mesh_raster_fast (-DMVR_DIAG build: per-workgroup s_memtime stamps of wave 0 into a
+buffer of their own), C2 workload.     python3 tools/diag_fast.py"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+diag = os.path.join(ROOT, "mvtn_amd", "libmvr_hip_diag.so")
+from mvtn_amd import build as b  # noqa: E402
+b.build_hip(out=diag, extra_flags=["-DMVR_DIAG"] + [x for x in os.environ.get("MVR_DIAG_EXTRA", "").split() if x])
+os.environ["MVR_LIB"] = diag
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, synthetic as syn  # noqa: E402
+lib = _lib.load()
+dev = torch.device("cuda:0")
+B, V, H = 16, 12, 224
+vl, fl = zip(*[syn.synthetic_mesh("M", i) for i in range(B)])
+packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl]), dev)
+az, el, di = syn.spherical_views(V)
+ta, te, td = (torch.from_numpy(np.tile(x, (B, 1))).to(dev) for x in (az, el, di))
+r = MVRenderer(V, H, pc_rendering=False, light_direction="fixed", rotation_check="off").eval()
+for _ in range(3):
+    r(packed, None, ta, te, td)
+nblocks = 8 * ((B * V + 7) // 8) * 28
+buf = torch.zeros((1 << 20) + 8 * 4096, dtype=torch.int64, device=dev)
+lib.mvr_diag_set_buffer.argtypes = [ctypes.c_void_p]
+lib.mvr_diag_set_buffer(buf.data_ptr())
+r(packed, None, ta, te, td)
+torch.cuda.synchronize()
+d = buf.cpu().numpy().reshape(-1, 8)[:nblocks].astype(np.float64)
+d = d[d[:, 5] > 0]
+tot = d[:, 5] - d[:, 0]
+print("workgroups with work: %d   cycles/workgroup mean %.0f max %.0f; listed faces mean %.0f; ambiguous pixels total %d" % (
+    len(d), tot.mean(), tot.max(), d[:, 6].mean(), d[:, 7].sum()))
+two = d[:, 2] > 0
+names = ["init (tables, key clear, first entries)", "raster (all segments, wave 0)", "wait for the other waves", "ambiguous pixels", "resolve + shade"]
+spans = [d[:, 1] - d[:, 0], d[:, 3] - d[:, 1], d[:, 4] - d[:, 3], 0 * tot, d[:, 5] - d[:, 4]]
+for nme, sp in zip(names, spans):
+    print("  %-42s %5.1f %%   mean %7.0f cycles" % (nme, 100 * sp.sum() / tot.sum(), sp.mean()))
+print("  two-segment workgroups: %.1f %%; their near segment (wave 0): mean %.0f cycles of raster %.0f" % (
+    100 * two.mean(), (d[two, 2] - d[two, 1]).mean(), (d[two, 3] - d[two, 1]).mean()))
+nl = d[:, 6]
+for lo, hi in [(1, 65), (65, 129), (129, 257), (257, 385), (385, 513), (513, 100000)]:
+    m = (nl >= lo) & (nl < hi)
+    if m.any():
+        print("    faces [%4d,%5d): %5.1f %% of wgs  total %7.0f  init %6.0f  raster %7.0f  wait %6.0f  resolve %7.0f" % (
+            lo, hi, 100 * m.mean(), tot[m].mean(), spans[0][m].mean(), spans[1][m].mean(), spans[2][m].mean(), spans[4][m].mean()))
