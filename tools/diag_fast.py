@@ -44,3 +44,10 @@ for lo, hi in [(1, 65), (65, 129), (129, 257), (257, 385), (385, 513), (513, 100
     if m.any():
         print("    faces [%4d,%5d): %5.1f %% of wgs  total %7.0f  init %6.0f  raster %7.0f  wait %6.0f  resolve %7.0f" % (
             lo, hi, 100 * m.mean(), tot[m].mean(), spans[0][m].mean(), spans[1][m].mean(), spans[2][m].mean(), spans[4][m].mean()))
+
+rs = buf.cpu().numpy().reshape(-1, 8)[(1 << 19) // 8:(1 << 19) // 8 + nblocks].astype(np.float64)
+rs = rs[rs[:, 5] > 0]
+if len(rs):
+    print("resolve+shade phases (wave 0 stamps), workgroups %d: covered px mean %.0f, winner faces mean %.0f max %.0f" % (len(rs), rs[:, 6].mean(), rs[:, 7].mean(), rs[:, 7].max()))
+    for nme, a_, b_ in [("scan + bg stores + flags", 0, 1), ("prefix", 1, 2), ("winner list", 2, 3), ("table build (gathers)", 3, 4), ("shade", 4, 5)]:
+        print("  %-28s mean %7.0f cycles" % (nme, (rs[:, b_] - rs[:, a_]).mean()))

@@ -7,6 +7,6 @@ for v in "$@"; do
   export MVR_LIB=/tmp/libvar.so
   rm -rf /tmp/var_prof
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/var_prof -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-pipelined > /tmp/var_bench.json 2>/dev/null
-  echo "== $v"
+  echo "== $v  $(MVR_DEBUG_OCC=1 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined 2>&1 | grep '\[mvr\]' | head -1 | cut -c1-75)"
   find /tmp/var_prof -name "*kernel_stats.csv" | head -1 | xargs grep "raster\|prepass" | cut -d, -f1-4 | sed 's/(.*)//'
 done
