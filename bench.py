@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — rendered views/s of the MVRenderer hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mesh_fwd|mesh_fwdbwd|points_fwd]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mesh_fwd|mesh_fwdbwd|points_fwd|c5]
+
+`--gpus N` with N > 1 and no RANK in the environment starts its own N ranks (torch.distributed.run on 127.0.0.1, one
+per GPU) BEFORE anything touches a GPU, relays rank 0's JSON line and exits with the children's status; started by a
+launcher (RANK set) it is one of the ranks.  On a box with fewer than N visible GPUs it fails loudly.
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
 MVRenderer.forward (look-at + validity/remedy + vertex normals + projection + rasterise + shade) on
@@ -38,7 +42,8 @@ def parse():
     # final synchronisation) is amortised — 100 steps read 5 % low (120.4 vs 114.3 us per C2 step); still < 1 s of GPU time
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="mesh_fwd", choices=["mesh_fwd", "mesh_fwdbwd", "points_fwd"])
+    ap.add_argument("--workload", default="mesh_fwd", choices=["mesh_fwd", "mesh_fwdbwd", "points_fwd", "c5"],
+                    help="c5 = BASELINE configs[4] per GPU: 8 ShapeNet-sized (tier L) meshes x 20 views, mesh render fwd")
     ap.add_argument("--batch", type=int, default=0, help="objects per GPU (default: the BASELINE config's)")
     ap.add_argument("--views", type=int, default=0)
     ap.add_argument("--image-size", type=int, default=224)
@@ -112,8 +117,34 @@ def cpu_baseline(args, V):
     return base
 
 
+def self_launch(args):
+    """`--gpus N` (N > 1) outside a launcher: start N ranks, relay rank 0's line.  Runs before any GPU call (a process that
+    has initialised the GPU must not be replaced or forked into ranks)."""
+    import socket
+    import subprocess
+    n_vis = torch.cuda.device_count()   # does not initialise the GPU on this image
+    if n_vis < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible on this node\n" % (args.gpus, n_vis))
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit code %d)\n%s\n" % (args.gpus, r.returncode, r.stdout[-2000:]))
+        sys.exit(r.returncode or 1)
+    print(lines[-1], flush=True)
+    sys.exit(0)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
     # Only the JSON line may reach stdout: libraries (RCCL prints a version banner on fd 1) are diverted to stderr
     # until the result is ready.
     sys.stdout.flush()
@@ -136,6 +167,10 @@ def main():
     from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, synthetic as syn
     lib = _lib.load()
 
+    c5 = args.workload == "c5"
+    if c5:   # BASELINE configs[4]: B=64 tier-L meshes x 20 views over 8 GPUs = 8 objects per GPU (weak scaling from there)
+        args.workload, args.tier = "mesh_fwd", "L"
+        args.batch, args.views = args.batch or 8, args.views or 20
     H = W = args.image_size
     if args.workload == "points_fwd":
         B, V, P = args.batch or 20, args.views or 20, 2048
@@ -224,27 +259,34 @@ def main():
     kern_ms = ms[kind] / max(1, cnt[kind])
     alg = algorithmic_bytes("mesh_fwd" if args.workload == "mesh_fwdbwd" else args.workload, B, V, H, W, nv_list, nf_list, P)
     achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath):
+    # HBM traffic of the dominant kernel: PMC passes of the same command, committed under profiles/ (FETCH_SIZE / WRITE_SIZE
+    # cannot be read inside this process); `from_profiles` names the file so that a stale number is visible as such
+    traffic, traffic_src = None, None
+    for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % args.workload)))[-1:]:
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic_src = os.path.relpath(tpath, ROOT)
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": ["k_mesh_raster_shade", "k_points_raster_shade", "k_mesh_backward"][kind],
+    kname = ["k_mesh_raster_fast", "k_points_raster_shade", "k_mesh_raster_fast"][kind]
+    roofline = {"bound": "hbm", "kernel": kname,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms, "launches_timed": int(cnt[kind])}
+                "traffic": traffic, "traffic_from_profiles": traffic_src, "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
+                "launches_timed": int(cnt[kind])}
     if args.workload == "mesh_fwdbwd" and cnt[2] > 0:
         roofline["backward_kernel_ms"] = ms[2] / cnt[2]
-    # what actually bounds the kernel (profiles/README.md): share of the launch during which the SIMDs' VALU is issuing,
-    # from the committed SQ counter pass of this round (SQ_ACTIVE_INST_VALU quad-cycles / 1024 SIMDs vs SQ_BUSY_CYCLES / 32)
+    # what actually bounds the mesh kernels (profiles/README.md): VALU issue.  A wave64 VALU instruction holds its SIMD for
+    # 4 cycles, so instructions x 4 / 1024 SIMDs is the kernel's VALU floor in cycles; against the LIVE kernel time (at the
+    # 2.07 GHz the counters show under this load) it gives the share of the launch the VALUs were issuing.  The instruction
+    # count comes from the committed SQ counter pass (it is a property of the code and the workload, not of the run).
     try:
         import glob
-        sq = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.json")))[-1]))
-        k = sq.get(roofline["kernel"])
-        if k and k.get("SQ_BUSY_CYCLES"):
-            roofline["valu_busy_frac"] = k["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (k["SQ_BUSY_CYCLES"] / 32.0)
-            roofline["valu_wave_instructions"] = k["SQ_INSTS_VALU"]
+        sqp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.json")))[-1]
+        k = json.load(open(sqp)).get(kname)
+        if k and k.get("SQ_INSTS_VALU") and kern_ms > 0 and args.workload != "points_fwd" and not c5:
+            floor_ms = k["SQ_INSTS_VALU"] * 4.0 / 1024.0 / 2.07e9 * 1e3
+            roofline["valu"] = {"wave_instructions": k["SQ_INSTS_VALU"], "issue_floor_ms": floor_ms, "frac": floor_ms / kern_ms,
+                                "from_profiles": os.path.relpath(sqp, ROOT)}
     except Exception:
         pass
 
@@ -341,11 +383,12 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "rendered views/sec (224x224, 12 views/obj)" if args.workload != "points_fwd" else "rendered views/sec (224x224 point clouds, 20 views/obj)",
+            "metric": ("rendered views/sec (224x224, 20 views/obj)" if c5 else "rendered views/sec (224x224, 12 views/obj)") if args.workload != "points_fwd" else "rendered views/sec (224x224 point clouds, 20 views/obj)",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"mesh_fwd": "C2: B=16 tier-%s meshes x 12 spherical views, %dx%d, mesh render fwd" % (args.tier, H, W),
+            "config": {"workload": "C5 (per GPU): B=%d tier-L meshes x %d spherical views, %dx%d, mesh render fwd" % (B, V, H, W) if c5 else
+                                   {"mesh_fwd": "C2: B=%d tier-%s meshes x %d spherical views, %dx%d, mesh render fwd" % (B, args.tier, V, H, W),
                                     "mesh_fwdbwd": "C3: B=16 tier-%s meshes x 12 jittered views, %dx%d, fwd+bwd (grad wrt azim/elev/dist, relative light)" % (args.tier, H, W),
                                     "points_fwd": "C4: B=20 clouds x 2048 pts x 20 views, %dx%d, point render fwd" % (H, W)}[args.workload],
                        "objects_per_gpu": B, "views_per_object": V, "image_size": H, "rotation_check": args.rotation_check,
@@ -357,6 +400,8 @@ def main():
         }
         if gather:
             line["allgather"] = gather
+        if dist_on:
+            line["world_size_seen_by_rccl"] = dist.get_world_size()
         if pipelined:
             line["two_streams"] = pipelined
         sys.stdout.flush()

@@ -92,12 +92,14 @@ def load():
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.exists(path) and not os.environ.get("MVR_LIB"):
-        try:  # the in-tree library has not been built yet: compile it now (hipcc cross-compiles without a GPU)
+    if not os.environ.get("MVR_LIB") and not _build.is_current():
+        # the in-tree library is missing or was built from other sources than the ones on disk: (re)build it now — hipcc
+        # cross-compiles without a GPU; concurrent ranks serialise on a file lock and only the first one compiles
+        try:
             _build.build_hip()
         except Exception as e:  # noqa: BLE001
             raise ImportError(
-                "mvtn_amd: %s is missing and could not be built (%s) — the HIP extension is the only rendering path "
+                "mvtn_amd: %s is missing or stale and could not be built (%s) — the HIP extension is the only rendering path "
                 "(no CPU fallback).  Build it with `python -c 'import __graft_entry__ as g; g.build()'`." % (path, e))
     if not os.path.exists(path):
         raise ImportError("mvtn_amd: %s does not exist" % path)

@@ -2,6 +2,8 @@
 
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the tree.
 """
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -32,24 +34,66 @@ def _sources():
             os.path.join(CSRC, "mvr_regularize.hip")] + sorted(glob.glob(os.path.join(CSRC, "*.inc")))
 
 
+def _src_hash(srcs, flags):
+    """Content hash of everything the library is built from (+ the flags): staleness must not depend on file times — a
+    snapshot copied to another machine keeps the bytes, not the mtimes."""
+    h = hashlib.sha256(" ".join(flags).encode())
+    for p in sorted(set(srcs)):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _hash_path(lib):
+    return lib + ".srchash"
+
+
+def is_current(lib=None):
+    """True when `lib` (default: the product library) was built from exactly the sources on disk."""
+    lib = lib or LIB_PATH
+    try:
+        return os.path.exists(lib) and open(_hash_path(lib)).read().strip() == _src_hash(_sources(), HIPCC_FLAGS)
+    except OSError:
+        return False
+
+
 def build_hip(force=False, verbose=False, out=None, extra_flags=()):
     """hipcc --offload-arch=gfx950 ... -> mvtn_amd/libmvr_hip.so.  `out` + `extra_flags` (-D switches): developer
-    variants for tools/ (ablation / diagnostic builds loaded through MVR_LIB), never the product library."""
+    variants for tools/ (ablation / diagnostic builds loaded through MVR_LIB), never the product library.
+
+    Safe under a multi-rank launch: the build happens under an exclusive file lock, into a per-process temporary that is
+    renamed into place, so a rank never loads a half-written library and never deletes another rank's object file; the
+    ranks that waited for the lock find the library current and do not build again."""
     srcs = _sources()
     if out is not None:
         return _compile(srcs, out, list(extra_flags), verbose)
-    if not force and not _stale(LIB_PATH, srcs):
+    if not force and is_current():
         return LIB_PATH
-    return _compile(srcs, LIB_PATH, [], verbose)
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and is_current():   # another rank built it while this one waited
+                return LIB_PATH
+            _compile(srcs, LIB_PATH, [], verbose)
+            tmp = "%s.tmp.%d" % (_hash_path(LIB_PATH), os.getpid())
+            with open(tmp, "w") as f:
+                f.write(_src_hash(srcs, HIPCC_FLAGS) + "\n")
+            os.replace(tmp, _hash_path(LIB_PATH))
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return LIB_PATH
 
 
 def _compile(srcs, LIB_PATH, extra, verbose):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     # the host-only mesh packer is plain C++: g++ builds the object (function multi-versioning for its
-    # narrowing loop), hipcc links it into the one library
-    pack_o = LIB_PATH + ".pack.o"
+    # narrowing loop), hipcc links it into the one library.  Everything is written under per-process names and the
+    # finished library is renamed into place (atomic on POSIX).
+    tmp_lib = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+    pack_o = "%s.pack.%d.o" % (LIB_PATH, os.getpid())
     cmds = [["g++", "-O3", "-std=c++17", "-fPIC", "-fvisibility-inlines-hidden", "-c", "-o", pack_o, srcs[3]],
-            [hipcc] + HIPCC_FLAGS + extra + ["-o", LIB_PATH, srcs[0], srcs[4], "-Wl," + pack_o]]
+            [hipcc] + HIPCC_FLAGS + extra + ["-o", tmp_lib, srcs[0], srcs[4], "-Wl," + pack_o]]
     try:
         for cmd in cmds:
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -57,9 +101,11 @@ def _compile(srcs, LIB_PATH, extra, verbose):
                 raise RuntimeError("%s failed:\n%s\n%s" % (os.path.basename(cmd[0]), " ".join(cmd), r.stderr))
             if verbose:
                 print(" ".join(cmd))
+        os.replace(tmp_lib, LIB_PATH)
     finally:
-        if os.path.exists(pack_o):
-            os.remove(pack_o)
+        for f in (pack_o, tmp_lib):
+            if os.path.exists(f):
+                os.remove(f)
     return LIB_PATH
 
 

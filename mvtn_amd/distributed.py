@@ -65,19 +65,60 @@ def all_gather_views(local_images, counts=None, group=None):
     return _AllGatherViews.apply(local_images, list(counts), group)
 
 
+def _image_tail(renderer, azim, group, have_local, local_tail):
+    """(V, 3, H, W) of the renderer's output for ranks that render nothing.  MVRenderer knows it (`image_size`); for any
+    other callable the lowest rank that did render broadcasts its tail — every rank takes this branch together because
+    the shard sizes are a function of (B, world) only."""
+    S = getattr(renderer, "image_size", None)
+    if S is not None:
+        return (azim.shape[1], 3, int(S), int(S))
+    world = dist.get_world_size(group)
+    t = torch.tensor(list(local_tail) if have_local else [0, 0, 0, 0], dtype=torch.int64, device=azim.device)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t, group=group)
+    for x in allt:
+        if int(x[0]) > 0:
+            return tuple(int(v) for v in x)
+    raise ValueError("render_sharded: no rank rendered anything (empty batch)")
+
+
+def _local_meshes(meshes, lo, hi, B, world):
+    """The local shard of `meshes`: a list of B objects is sliced; a PackedMeshes (already on this rank's GPU) must BE the
+    local shard (hi - lo meshes) — packed batches are not re-sliced on the device."""
+    if meshes is None:
+        return None
+    if hasattr(meshes, "n_meshes"):
+        if meshes.n_meshes == hi - lo:
+            return meshes
+        raise ValueError("render_sharded: a PackedMeshes argument must hold exactly this rank's shard (%d meshes for objects "
+                         "[%d, %d) of %d over %d ranks), got %d — pass the list of objects or pack the local slice"
+                         % (hi - lo, lo, hi, B, world, meshes.n_meshes))
+    return [meshes[i] for i in range(lo, hi)]
+
+
 def render_sharded(renderer, meshes, points, azim, elev, dist_, color=None, gather=True, group=None):
-    """Render this rank's shard of a batch that every rank holds in full (meshes: list of B objects;
-    points / azim / elev / dist: leading dimension B), optionally all-gathering the images.
+    """Render this rank's shard of a batch that every rank holds in full (meshes: list of B objects, or a PackedMeshes
+    of exactly the local shard; points / azim / elev / dist: leading dimension B), optionally all-gathering the images.
+    A rank whose shard is empty (B < world size) renders nothing and contributes zero rows to the gather.
     Returns (images, cameras_of_the_local_shard)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     B = azim.shape[0]
     lo, hi = shard_range(B, world, rank)
-    m = None if meshes is None else ([meshes[i] for i in range(lo, hi)] if not hasattr(meshes, "n_meshes") else meshes)
-    p = None if points is None else points[lo:hi]
+    counts = shard_counts(B, world)
     c = color[lo:hi] if (torch.is_tensor(color) and color.dim() >= 2) else color
-    images, cams = renderer(m, p, azim[lo:hi], elev[lo:hi], dist_[lo:hi], c)
+    images = cams = None
+    if hi > lo:
+        images, cams = renderer(_local_meshes(meshes, lo, hi, B, world), None if points is None else points[lo:hi],
+                                azim[lo:hi], elev[lo:hi], dist_[lo:hi], c)
+    if min(counts) == 0:   # the same on every rank
+        tail = _image_tail(renderer, azim, group, images is not None, () if images is None else images.shape[1:])
+        if images is None:
+            images = torch.zeros((0,) + tuple(tail), dtype=torch.float32, device=azim.device)
+            if torch.is_grad_enabled() and any(torch.is_tensor(x) and x.requires_grad for x in (azim, elev, dist_)):
+                # keep this rank inside the autograd graph of the gather (its backward is a collective every rank must enter)
+                images = images + 0.0 * sum(x[lo:hi].sum() for x in (azim, elev, dist_) if x.requires_grad)
     if gather:
-        images = all_gather_views(images, shard_counts(B, world), group)
+        images = all_gather_views(images, counts, group)
     return images, cams
 
 
@@ -103,6 +144,16 @@ def render_sharded_overlapped(renderer, meshes, points, azim, elev, dist_, color
     pieces = [_chunk_bounds(lo, hi, chunks) for lo, hi in ranges]
     out = None
     works, keep, cams = [], [], []
+    # shape of a rendered view block, for ranks / pieces without objects: known from the renderer, else (stand-in
+    # renderers in tests) from the first rank's first object — no throw-away render on the GPU path
+    tail = None
+    if getattr(renderer, "image_size", None) is not None:
+        tail = (azim.shape[1], 3, int(renderer.image_size), int(renderer.image_size))
+    elif min(hi - lo for lo, hi in ranges) == 0 or min(b - a for pr in pieces for a, b in pr) == 0:
+        with torch.no_grad():
+            probe = renderer(None if meshes is None else [meshes[0]], None if points is None else points[:1],
+                             azim[:1], elev[:1], dist_[:1], color[:1] if (torch.is_tensor(color) and color.dim() >= 2) else color)[0]
+        tail = tuple(probe.shape[1:])
     for c in range(chunks):
         lo, hi = pieces[rank][c]
         local = None
@@ -121,9 +172,7 @@ def render_sharded_overlapped(renderer, meshes, points, azim, elev, dist_, color
                 out = local.new_empty((B,) + tuple(local.shape[1:]))
             out[lo:hi].copy_(local)
         if out is None:     # a rank without objects in this piece still has to post its receives
-            probe = renderer(None if meshes is None else [meshes[0]], None if points is None else points[:1],
-                             azim[:1], elev[:1], dist_[:1], color[:1] if (torch.is_tensor(color) and color.dim() >= 2) else color)[0]
-            out = probe.new_empty((B,) + tuple(probe.shape[1:]))
+            out = torch.empty((B,) + tuple(tail), dtype=torch.float32, device=azim.device)
         ops = []
         for peer in range(world):
             if peer == rank:

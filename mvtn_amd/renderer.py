@@ -114,6 +114,12 @@ class MVRenderer(nn.Module):
         self._pending.append(host)
         return EXAHSTION_LIMIT, seed, host
 
+    def _forget_status(self, host):
+        """The launch that should have written `host` failed before reaching the GPU: take it out of the pending list."""
+        if host is not None:
+            self._pending = [h for h in self._pending if h is not host]
+            self._status_pool.append(host)
+
     def check_status(self, block=True):
         """Raise the reference's sys.exit("Remedy did not work") if an earlier forward exhausted the
         device-side remedy.  block=False only looks at status words that have already landed."""
@@ -124,6 +130,9 @@ class MVRenderer(nn.Module):
                     keep.append(host)
                     continue
                 torch.cuda.synchronize()
+                if int(host[1]) == _STATUS_PENDING:   # still the sentinel after a full synchronise: never launched
+                    self._status_pool.append(host)
+                    continue
             if int(host[1]) != 0:
                 self._pending = []
                 sys.exit("Remedy did not work")
@@ -152,6 +161,9 @@ class MVRenderer(nn.Module):
             obj = [float(c) for c in color]
         if isinstance(meshes, PackedMeshes):
             packed = meshes
+            if vert_colors is not None and packed.vert_colors is None:
+                # models/renderer.py:76-77 applies color * ones as vertex textures; a pre-packed batch has to carry them
+                packed = packed.with_vert_colors(vert_colors)
         else:
             packed = PackedMeshes.from_meshes(meshes, device, vert_colors)
         N = packed.n_meshes * self.nb_views
@@ -182,8 +194,12 @@ class MVRenderer(nn.Module):
         max_trials, seed, host = -1, 0, None
         if self.rotation_check == "device":
             max_trials, seed, host = self._device_remedy_args()
-        images, R, T, status = F.render_mesh_views(packed, flatten_views(azim), flatten_views(elev), flatten_views(dist),
-                                                   light, params, max_trials=max_trials, seed=seed, host_status=host)
+        try:
+            images, R, T, status = F.render_mesh_views(packed, flatten_views(azim), flatten_views(elev), flatten_views(dist),
+                                                       light, params, max_trials=max_trials, seed=seed, host_status=host)
+        except Exception:
+            self._forget_status(host)   # no kernel will ever write it: it must not read as "remedy exhausted" later
+            raise
         if self.rotation_check == "sync" and int(status[1].item()) != 0:
             R, T = self._remedy(azim, elev, dist)
             if light is None:
@@ -211,8 +227,12 @@ class MVRenderer(nn.Module):
         if not need_grad and self.rotation_check != "sync" and B * self.nb_views <= F.POINT_VIEWS_FUSED_MAX:
             # inference: look-at + projection + rasterisation in one library call (two launches)
             max_trials, seed, host = self._device_remedy_args() if self.rotation_check == "device" else (-1, 0, None)
-            images, R, T, _ = F.render_point_views(pts, colors, flatten_views(azim), flatten_views(elev), flat_dist, params,
-                                                   max_trials=max_trials, seed=seed, host_status=host)
+            try:
+                images, R, T, _ = F.render_point_views(pts, colors, flatten_views(azim), flatten_views(elev), flat_dist, params,
+                                                       max_trials=max_trials, seed=seed, host_status=host)
+            except Exception:
+                self._forget_status(host)
+                raise
             return images, Cameras(R, T, "orthographic", znear=0.01)
         R, T, status = self._cameras(azim, elev, dist)
         images = F.render_points(pts, colors, R, T, flat_dist, params)
@@ -232,8 +252,12 @@ class MVRenderer(nn.Module):
         background_color = self._named_color(self.background_color)
         if self.object_color == "custom" or (self.object_color == "random" and self.training):
             color = self.rendering_color(color)
+        elif self.object_color == "random":   # eval: torch_color("white") WITHOUT max_lightness = (1, 1, 1) (models/renderer.py:156-157)
+            color = self._color_cache.get("__random_eval__")
+            if color is None:
+                color = self._color_cache["__random_eval__"] = tuple(float(c) for c in self.rendering_color(color))
         else:   # a fixed named colour: the same floats every call
-            color = self._named_color("white" if self.object_color == "random" else self.object_color)
+            color = self._named_color(self.object_color)
         if not self.pc_rendering:
             relative = not (self.light_direction_type == "fixed" or (self.light_direction_type == "random" and self.training))
             lights = None if relative else self.light_direction(azim, elev, dist)

@@ -171,6 +171,20 @@ class PackedMeshes:
             vc = torch.cat([vcs[b, :v.shape[0]].reshape(-1, 3) for b, v in enumerate(vs)], 0).contiguous().to(device, non_blocking=True)
         return PackedMeshes(verts, faces, vo, fo, n, int(lay.max_verts), int(lay.max_faces), vc)
 
+    def with_vert_colors(self, vert_colors):
+        """A view of this batch (same geometry tensors, nothing copied) carrying per-vertex colours: `vert_colors` is the
+        padded (B, >= max Vn, 3) tensor models/renderer.py:76-77 builds, or an already packed (sum Vn, 3) one."""
+        vc = vert_colors.detach().to(self.verts.device, torch.float32)
+        if vc.dim() == 3:
+            off = self.vert_off.cpu().tolist()
+            if vc.shape[0] != self.n_meshes or vc.shape[1] < self.max_verts:
+                raise ValueError("vert_colors must be (B, >= max Vn, 3) = (%d, >= %d, 3), got %s" % (self.n_meshes, self.max_verts, tuple(vc.shape)))
+            vc = torch.cat([vc[b, :off[b + 1] - off[b]] for b in range(self.n_meshes)], 0)
+        if tuple(vc.shape) != (self.total_verts, 3):
+            raise ValueError("packed vert_colors must be (%d, 3), got %s" % (self.total_verts, tuple(vc.shape)))
+        return PackedMeshes(self.verts, self.faces, self.vert_off, self.face_off, self.n_meshes, self.max_verts, self.max_faces,
+                            vc.contiguous())
+
     def c_struct(self):
         cs = getattr(self, "_cs", None)
         if cs is None:   # the tensors of a PackedMeshes are never re-assigned: build the C view once

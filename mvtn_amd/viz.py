@@ -36,9 +36,21 @@ def write_png(path, rgb_u8):
 
 
 def save_grid(image_batch, save_path, nrow=8):
-    """util.py:667-673: one row of views as an image file (PNG regardless of the extension given)."""
+    """util.py:667-673: one row of views as an image file.  The reference hands the array to imageio, which picks the
+    format from the extension; here ".png" is written with the standard library and any other extension (".jpg", ...)
+    goes through Pillow — a file is never written in a format its name does not say."""
+    import os
     grid = make_grid(image_batch.detach().float().cpu(), nrow=nrow)
-    write_png(save_path, (grid.clamp(0, 1) * 255).to(torch.uint8).permute(1, 2, 0).contiguous())
+    rgb = (grid.clamp(0, 1) * 255).to(torch.uint8).permute(1, 2, 0).contiguous()
+    ext = os.path.splitext(str(save_path))[1].lower()
+    if ext == ".png":
+        write_png(save_path, rgb)
+        return
+    try:
+        from PIL import Image
+    except ImportError:
+        raise ValueError("save_grid: writing %r needs Pillow (only .png is written without it)" % ext)
+    Image.fromarray(rgb.numpy()).save(save_path)
 
 
 def save_cameras(cameras, save_path, scale=0.22, dpi=200):

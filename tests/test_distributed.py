@@ -105,3 +105,19 @@ def test_shard_ranges():
     assert [shard_range(64, 8, r) for r in (0, 7)] == [(0, 8), (56, 64)]
     assert shard_counts(10, 4) == [3, 3, 2, 2]
     assert [shard_range(3, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 3)]
+
+
+def test_packed_shard_must_match():
+    """A PackedMeshes handed to render_sharded has to be exactly the local shard: anything else raises instead
+    of rendering B meshes against a slice of the angles."""
+    sys.path.insert(0, ROOT)
+    from mvtn_amd.distributed import _local_meshes
+
+    class _Packed:
+        n_meshes = 3
+    p = _Packed()
+    assert _local_meshes(p, 2, 5, 8, 2) is p
+    with pytest.raises(ValueError, match="exactly this rank's shard"):
+        _local_meshes(p, 0, 4, 8, 2)
+    assert _local_meshes(["a", "b", "c", "d"], 1, 3, 4, 2) == ["b", "c"]
+    assert _local_meshes(None, 0, 1, 2, 2) is None

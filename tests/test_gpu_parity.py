@@ -1056,3 +1056,126 @@ def test_stream_pipeline_gives_the_same_images():
     for i, g in enumerate(got):
         assert torch.equal(g, want[i % len(jobs)]), i
     assert torch.isfinite(total).all()
+
+
+# ---- round 2: the fast rasteriser (exact edge signs + provably ordered affine inverse depth) --------------------------
+
+@pytest.mark.parametrize("name,specs,V,size,dist,jitter", [
+    ("C2 slice", [("M", 0), ("M", 1), ("M", 2), ("M", 3)], 12, 224, 2.2, False),
+    ("tier L, 20 views", [("L", 2), ("L", 3)], 20, 224, 2.2, True),
+    ("ragged + CAD soup", [("S", 3), ("L", 4), ("soup", 5), ("M", 6)], 6, 224, 2.2, True),
+    ("close-up", [("M", 0), ("M", 1)], 12, 224, 1.2, True),
+    ("camera inside the object", [("M", 0), ("M", 1)], 12, 224, 0.8, True),
+    ("odd image size", [("S", 10), ("soup", 11)], 2, 37, 2.2, True),
+    ("128", [("M", 7)], 4, 128, 2.2, False),
+])
+def test_fast_rasteriser_equals_exact_kernel(name, specs, V, size, dist, jitter):
+    """The default mesh forward (k_mesh_raster_fast: fall-back to the exact body per strip) against MVR_RASTER_EXACT_ONLY
+    (k_mesh_raster_shade on every strip): pixel->face maps identical, images within the colour tolerance (the two shade
+    with differently ordered but equivalent arithmetic), and the number of strips the fast path gave up on."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = _mesh_batch(specs)
+    B = len(vl)
+    az, el, di = _views(B, V if V in (4, 6, 12, 20) else 4, 7, jitter)
+    az, el = az[:, :V], el[:, :V]
+    di = np.full((B, V), dist, np.float32) + (di[:, :V] - 2.2 if jitter else 0)
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
+    obj = bg = (0.99999,) * 3
+    out = {}
+    for mode in ("fast", "exact"):
+        params = F.mesh_params(V, size, 1, obj, bg, exact_raster=(mode == "exact"))
+        img, p2f, cnt = F.render_meshes_fragments(packed, R, T, light, params, return_redo=True)
+        torch.cuda.synchronize()
+        out[mode] = (img.cpu().numpy(), p2f.cpu().numpy(), int(cnt.item()))
+    n_strips = B * V * ((size + 7) // 8)
+    print("%s: %d of %d strips fell back to the exact rasteriser" % (name, out["fast"][2], n_strips))
+    assert np.array_equal(out["fast"][1], out["exact"][1]), "%d pixels differ" % int((out["fast"][1] != out["exact"][1]).sum())
+    assert np.abs(out["fast"][0] - out["exact"][0]).max() <= 5e-5
+    if "soup" not in str(specs) and dist >= 1.2:
+        assert out["fast"][2] <= n_strips // 100, "ordinary meshes should almost never need the exact path"
+    if "soup" in str(specs):
+        assert out["fast"][2] > 0, "coincident double-sided faces must be undecidable for the fast path"
+
+
+def test_full_size_c2_all_meshes_against_the_oracle(oracle):
+    """BASELINE configs[1] at FULL size: all 16 tier-M meshes x 12 spherical views at 224^2 against the oracle
+    (round 1 checked a 2-mesh slice): pixel->face bit-exact, images within 1e-4."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    B, V, size = 16, 12, 224
+    vl, fl = _mesh_batch([("M", s) for s in range(B)])
+    az, el, di = _views(B, V, 0, jitter=False)
+    obj = bg = (0.99999,) * 3
+    want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, mode=1)
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    params = F.mesh_params(V, size, 1, obj, bg)
+    img, p2f = F.render_meshes_fragments(packed, R, T, _t(np.array([[0.0, 1.0, 0.0]], np.float32)), params)
+    torch.cuda.synchronize()
+    assert np.array_equal(p2f.cpu().numpy(), want["pix_to_face"])
+    assert np.abs(img.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+
+
+def test_full_size_c4_all_clouds_against_the_oracle(oracle):
+    """BASELINE configs[3] at FULL size: 20 clouds x 2048 points x 20 views at 224^2 against the oracle."""
+    from mvtn_amd import functional as F
+    B, P, V, size = 20, 2048, 20, 224
+    clouds = []
+    for i in range(B):
+        v, f = syn.synthetic_mesh("M", i)
+        clouds.append(syn.surface_points(v, f, P, seed=i))
+    pts = np.stack(clouds)
+    az, el, _ = _views(B, V, 0, jitter=False)
+    di = np.full((B, V), 1.0, np.float32)
+    obj = bg = (0.99999,) * 3
+    want = oracle.render_points(pts, az, el, di, size, radius=0.006, obj_color=obj, bg_color=bg)
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    params = F.points_params(B, P, V, size, 0.006, obj, bg)
+    img, p2p = F.render_points_fragments(_t(pts), None, R, T, _t(di.reshape(-1)), params)
+    torch.cuda.synchronize()
+    assert np.array_equal(p2p.cpu().numpy().reshape(want["idx"].shape), want["idx"])
+    assert np.abs(img.cpu().numpy() - want["images"]).max() <= 1e-6
+
+
+def test_random_object_colour_in_eval_is_pure_white(oracle):
+    """models/renderer.py:156-157: object_color="random" in eval() renders torch_color("white") WITHOUT max_lightness,
+    i.e. (1, 1, 1) — not the 0.99999 of the named colours (VERDICT r1 weak #9)."""
+    from mvtn_amd import MVRenderer, Meshes
+    v, f = syn.synthetic_mesh("S", 1)
+    az, el, di = syn.circular_views(4)
+    r = MVRenderer(4, 64, pc_rendering=False, object_color="random", light_direction="fixed").eval()
+    img, _ = r([Meshes([v], [f])], None, _t(az[None]), _t(el[None]), _t(di[None]))
+    want = oracle.render_meshes([v], [f], az[None], el[None], di[None], 64, obj_color=(1.0, 1.0, 1.0), bg_color=(0.99999,) * 3)
+    assert np.abs(img.cpu().numpy() - want["images"]).max() <= 2e-5     # (1e-5 apart from the 0.99999 rendering: must be the 1.0 one)
+    wrong = oracle.render_meshes([v], [f], az[None], el[None], di[None], 64, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
+    cov = want["pix_to_face"] >= 0
+    d_right = np.abs(img.cpu().numpy() - want["images"]).reshape(4, 3, 64, 64).max(1)[cov].mean()
+    d_wrong = np.abs(img.cpu().numpy() - wrong["images"]).reshape(4, 3, 64, 64).max(1)[cov].mean()
+    assert d_right < d_wrong
+
+
+def test_custom_vertex_colours_with_a_packed_batch(oracle):
+    """object_color="custom" + a pre-packed PackedMeshes: the per-vertex colours must reach the kernel (ADVICE r1: they
+    were dropped and the image came out white); same image as handing the list of meshes."""
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes
+    vl, fl = _mesh_batch([("S", 0), ("S", 1)])
+    B, V, size = 2, 3, 64
+    rng = np.random.default_rng(3)
+    mx = max(len(v) for v in vl)
+    col = rng.uniform(0.1, 0.9, (B, mx, 3)).astype(np.float32)
+    az, el, di = _views(B, 4, 2)
+    az, el, di = az[:, :V], el[:, :V], di[:, :V]
+    r = MVRenderer(V, size, pc_rendering=False, object_color="custom", light_direction="fixed").eval()
+    meshes = [Meshes([v], [f]) for v, f in zip(vl, fl)]
+    a, e, d, c = _t(az), _t(el), _t(di), _t(col)
+    img_list, _ = r(meshes, None, a, e, d, c)
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    img_packed, _ = r(packed, None, a, e, d, c)
+    assert torch.equal(img_list, img_packed)
+    vc = np.concatenate([col[b, :len(v)] for b, v in enumerate(vl)], 0)
+    want = oracle.render_meshes(vl, fl, az, el, di, size, vert_colors=vc, bg_color=(0.99999,) * 3)
+    assert np.abs(img_packed.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+    assert float((img_packed - 0.99999).abs().max()) > 0.05      # not a white render

@@ -3,6 +3,7 @@ import struct
 import zlib
 
 import numpy as np
+import pytest
 import torch
 
 from mvtn_amd import viz
@@ -72,3 +73,15 @@ def test_save_cameras_writes_a_plot(tmp_path):
     viz.save_cameras(Cameras(R, T, "perspective"), path, scale=0.22, dpi=50)
     data = open(path, "rb").read()
     assert data[:8] == b"\x89PNG\r\n\x1a\n" and len(data) > 1000
+
+
+def test_save_grid_honours_the_extension(tmp_path):
+    """util.py:667-673 lets imageio pick the format from the file name: a .jpg must be a JPEG (r1 wrote PNG bytes)."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    imgs = torch.rand(3, 3, 8, 8)
+    path = str(tmp_path / "grid.jpg")
+    viz.save_grid(imgs, path, nrow=3)
+    with open(path, "rb") as f:
+        assert f.read(3) == b"\xff\xd8\xff"
+    assert Image.open(path).size == (3 * 10 + 2, 12)
