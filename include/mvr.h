@@ -78,6 +78,10 @@ typedef struct mvr_mesh_params {
   float ambient, diffuse, specular, shininess; /* DirectionalLights/Materials defaults .5 .3 .2 64 */
   float obj_color[3];     /* rendering_color(), models/renderer.py:153-160 */
   float bg_color[3];      /* BlendParams(background_color), :102 */
+  float z_clip;           /* PyTorch3D >= 0.5 clips faces at view depth znear / 2 = 0.5 for the perspective cameras of this
+                             path (MeshRasterizer: z_clip_value); 0 = no clipping (PyTorch3D < 0.5).  Faces wholly nearer
+                             than the plane are culled as the reference does; faces that STRADDLE it are rasterised whole
+                             and counted (mvr_mesh_clip_straddlers): a forward is clip-exact iff that count is 0 */
 } mvr_mesh_params;
 
 typedef struct mvr_points_params {
@@ -172,6 +176,12 @@ int mvr_pack_meshes_host(const mvr_pack_layout *layout, const float *const *vert
 
 /* Scratch the mesh calls need (vertex attributes, projected vertices, backward partials). */
 size_t mvr_mesh_workspace_bytes(const mvr_mesh_batch *meshes, const mvr_mesh_params *params);
+
+/* How many faces of the LAST forward that used `workspace` straddled the z-clip plane (summed over the views): they were
+ * rasterised unclipped, i.e. as PyTorch3D < 0.5 would.  0 (always, for unit-normalised objects at distance >= 1.5):
+ * the images are what the clipping reference renders.  count: 1 device int. */
+int mvr_mesh_clip_straddlers(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const void *workspace, size_t workspace_bytes,
+                             int32_t *count, mvr_stream_t stream);
 
 /* Diagnostics: how many (view, strip) tiles of the LAST forward that used `workspace` the fast rasteriser could not
  * decide and handed to the exact-arithmetic kernel (coincident / intersecting faces, extreme depths).  Only meaningful

@@ -27,7 +27,7 @@ class MeshParams(ctypes.Structure):  # struct mvr_mesh_params
                 ("flags", ctypes.c_int32), ("n_light", ctypes.c_int32), ("strip_rows", ctypes.c_int32),
                 ("fov_deg", ctypes.c_float), ("ambient", ctypes.c_float), ("diffuse", ctypes.c_float),
                 ("specular", ctypes.c_float), ("shininess", ctypes.c_float),
-                ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3)]
+                ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3), ("z_clip", ctypes.c_float)]
 
 
 class PointsParams(ctypes.Structure):  # struct mvr_points_params
@@ -67,6 +67,7 @@ PROTOTYPES = {
     "mvr_camera_position": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     "mvr_camera_position_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "mvr_mesh_workspace_bytes": (ctypes.c_size_t, [_MB, _MP]),
+    "mvr_mesh_clip_straddlers": (ctypes.c_int, [_MB, _MP, _vp, ctypes.c_size_t, _vp, _vp]),
     "mvr_mesh_redo_count": (ctypes.c_int, [_MB, _MP, _vp, ctypes.c_size_t, _vp, _vp]),
     "mvr_vertex_normals": (ctypes.c_int, [_MB, _vp, _vp, ctypes.c_size_t, _vp]),
     "mvr_render_meshes_forward": (ctypes.c_int, [_MB, _MP, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),

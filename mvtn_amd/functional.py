@@ -125,8 +125,12 @@ def camera_position_from_spherical_angles(distance, elevation, azimuth):
 # ---------------------------------------------------------------------------------------------
 
 def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backfaces=False, perspective_correct=True,
-                fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, strip_rows=0, exact_raster=False):
-    """`exact_raster`: skip the fast rasteriser (MVR_RASTER_EXACT_ONLY); the images are the same either way."""
+                fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, strip_rows=0, exact_raster=False, z_clip=None):
+    """`exact_raster`: skip the fast rasteriser (MVR_RASTER_EXACT_ONLY); the images are the same either way.
+    `z_clip`: view depth of PyTorch3D >= 0.5's face clipping; None = the reference's rule (znear / 2 = 0.5 when
+    perspective_correct — MeshRasterizer only clips for perspective cameras with it on —, else off); 0 = off."""
+    if z_clip is None:
+        z_clip = 0.5 if perspective_correct else 0.0
     H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
     flags = (_lib.MVR_CULL_BACKFACES if cull_backfaces else 0) | (_lib.MVR_PERSPECTIVE_CORRECT if perspective_correct else 0)
     flags |= _lib.MVR_RASTER_EXACT_ONLY if exact_raster else 0
@@ -134,6 +138,7 @@ def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backface
     for k in range(3):
         p.obj_color[k] = float(obj_color[k])
         p.bg_color[k] = float(bg_color[k])
+    p.z_clip = float(z_clip)
     return p
 
 
@@ -280,9 +285,10 @@ def render_mesh_views(packed: PackedMeshes, azim, elev, dist, light_dir, params,
                                   max_trials, seed, host_status, need_grad)
 
 
-def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params, return_redo=False):
+def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params, return_redo=False, return_straddlers=False):
     """(images, pix_to_face (N,H,W) int32 LOCAL face index / -1) without autograd — for parity tests.
-    `return_redo`: also the number of (view, strip) tiles the fast rasteriser left to the exact kernel (a device int)."""
+    `return_redo`: also the number of (view, strip) tiles the fast rasteriser left to the exact kernel (a device int);
+    `return_straddlers`: also the number of faces that straddled the z-clip plane (rasterised unclipped)."""
     lib = _lib.load()
     R, T, light = _f32c(R), _f32c(T), _f32c(light_dir)
     _require_cuda(R, T, light, packed.verts)
@@ -294,11 +300,16 @@ def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params, retur
     p2f = torch.empty(B * V, H, W, dtype=torch.int32, device=R.device)
     _lib.check(lib.mvr_render_meshes_forward(mb, params, R.data_ptr(), T.data_ptr(), light.data_ptr(), images.data_ptr(),
                                              p2f.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "mvr_render_meshes_forward")
+    extra = ()
     if return_redo:
         cnt = torch.zeros(1, dtype=torch.int32, device=R.device)
         _lib.check(lib.mvr_mesh_redo_count(mb, params, ws.data_ptr(), ws_bytes, cnt.data_ptr(), _stream()), "mvr_mesh_redo_count")
-        return images, p2f, cnt
-    return images, p2f
+        extra += (cnt,)
+    if return_straddlers:
+        cnt = torch.zeros(1, dtype=torch.int32, device=R.device)
+        _lib.check(lib.mvr_mesh_clip_straddlers(mb, params, ws.data_ptr(), ws_bytes, cnt.data_ptr(), _stream()), "mvr_mesh_clip_straddlers")
+        extra += (cnt,)
+    return (images, p2f) + extra
 
 
 def render_points_fragments(points, colors, R, T, dist, params):

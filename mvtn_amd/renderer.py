@@ -34,7 +34,7 @@ _STATUS_PENDING = -1   # sentinel in the pinned status words until the look-at k
 class MVRenderer(nn.Module):
     def __init__(self, nb_views, image_size=224, pc_rendering=True, object_color="white", background_color="white",
                  faces_per_pixel=1, points_radius=0.006, points_per_pixel=1, light_direction="random",
-                 cull_backfaces=False, *, perspective_correct=True, rotation_check="device", strip_rows=0):
+                 cull_backfaces=False, *, perspective_correct=True, rotation_check="device", strip_rows=0, z_clip=None):
         super().__init__()
         self.nb_views = nb_views
         self.image_size = image_size
@@ -47,6 +47,7 @@ class MVRenderer(nn.Module):
         self.light_direction_type = light_direction
         self.cull_backfaces = cull_backfaces
         self.perspective_correct = perspective_correct
+        self.z_clip = z_clip   # None: the reference's rule (PyTorch3D >= 0.5: znear / 2 = 0.5 with perspective_correct); 0: no clipping
         if rotation_check not in ("device", "sync", "off"):
             raise ValueError("rotation_check must be 'device', 'sync' or 'off'")
         self.rotation_check = rotation_check
@@ -180,14 +181,14 @@ class MVRenderer(nn.Module):
                     self._light_cache[key] = light
         n_light = N if light is None else light.shape[0]
         pkey = (n_light, tuple(obj), tuple(float(c) for c in background_color), bool(self.cull_backfaces),
-                bool(self.perspective_correct), self.strip_rows, self.nb_views, self.image_size)
+                bool(self.perspective_correct), self.strip_rows, self.nb_views, self.image_size, self.z_clip)
         params = self._params_cache.get(pkey)
         if params is None:
             if len(self._params_cache) > 64:
                 self._params_cache.clear()
             params = self._params_cache[pkey] = F.mesh_params(self.nb_views, self.image_size, n_light, pkey[1], pkey[2],
                                                               cull_backfaces=pkey[3], perspective_correct=pkey[4],
-                                                              strip_rows=self.strip_rows)
+                                                              strip_rows=self.strip_rows, z_clip=self.z_clip)
         if azim.numel() != N:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (packed.n_meshes, self.nb_views))
         # look-at (+ remedy) -> light -> rasterise + shade as ONE autograd node

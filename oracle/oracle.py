@@ -118,9 +118,10 @@ def render_meshes(verts_list, faces_list, azim, elev, dist, image_size, light_di
                   obj_color=(1.0, 1.0, 1.0), bg_color=(1.0, 1.0, 1.0), vert_colors=None,
                   perspective_correct=True, cull_backfaces=False, fov=60.0,
                   ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0,
-                  mode=1, fixed_p2f=None, dtype=np.float32, R=None, T=None, return_fragments=True):
-    """Restates models/renderer.py:65-114.  azim/elev/dist: (B,V) degrees.
-    Returns dict(images (B,V,3,H,W), pix_to_face (N,H,W) local idx, zbuf, bary (N,H,W,3), R, T)."""
+                  mode=1, fixed_p2f=None, dtype=np.float32, R=None, T=None, return_fragments=True, z_clip=0.0):
+    """Restates models/renderer.py:65-114.  azim/elev/dist: (B,V) degrees.  z_clip > 0: PyTorch3D >= 0.5's face clipping
+    at that view depth (MeshRasterizer uses znear / 2 = 0.5 for the perspective cameras of the mesh path); 0 = off.
+    Returns dict(images (B,V,3,H,W), pix_to_face (N,H,W) local idx, zbuf, bary (N,H,W,3), R, T, straddlers (N,))."""
     sfx, cty = _sfx(dtype)
     azim = np.asarray(azim, dtype)
     B, V = azim.shape
@@ -141,14 +142,15 @@ def render_meshes(verts_list, faces_list, azim, elev, dist, image_size, light_di
     zbuf = np.empty((N, H, W), dtype) if return_fragments else None
     bary = np.empty((N, H, W, 3), dtype) if return_fragments else None
     fixed = None if fixed_p2f is None else np.ascontiguousarray(fixed_p2f, np.int32)
+    straddlers = np.zeros(N, np.int32)
     getattr(lib(), "orc_render_meshes" + sfx)(
         ctypes.c_int(B), ctypes.c_int(V), ctypes.c_int(H), ctypes.c_int(W),
         _ptr(verts), _ptr(faces), _ptr(vert_off), _ptr(face_off), _ptr(R), _ptr(T),
         _ptr(light), ctypes.c_int(light.shape[0]), _ptr(vc), _ptr(oc), _ptr(bg),
         ctypes.c_int(int(perspective_correct)), ctypes.c_int(int(cull_backfaces)),
         cty(fov), cty(ambient), cty(diffuse), cty(specular), cty(shininess),
-        ctypes.c_int(mode), _ptr(fixed), _ptr(images), _ptr(p2f), _ptr(zbuf), _ptr(bary))
-    return dict(images=images, pix_to_face=p2f, zbuf=zbuf, bary=bary, R=R, T=T)
+        ctypes.c_int(mode), _ptr(fixed), cty(z_clip), _ptr(straddlers), _ptr(images), _ptr(p2f), _ptr(zbuf), _ptr(bary))
+    return dict(images=images, pix_to_face=p2f, zbuf=zbuf, bary=bary, R=R, T=T, straddlers=straddlers)
 
 
 def render_points(points, azim, elev, dist, image_size, radius=0.006, obj_color=(1.0, 1.0, 1.0),

@@ -42,7 +42,7 @@ for case in range(n_cases):
     packed = PackedMeshes.from_meshes(Meshes(vl, fl), dev)
     t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
     R, T = F.look_at_view_transform(t(di.reshape(-1)), t(el.reshape(-1)), t(az.reshape(-1)))
-    params = F.mesh_params(V, size, 1, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip)
+    params = F.mesh_params(V, size, 1, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip, z_clip=0.0)
     img, p2f = F.render_meshes_fragments(packed, R, T, t([[0, 1, 0]]), params)
     p2f = p2f.cpu().numpy(); img = img.cpu().numpy()
     nd = int((p2f != want["pix_to_face"]).sum())

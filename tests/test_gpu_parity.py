@@ -931,7 +931,8 @@ def test_random_configurations_slice(oracle, seed):
                                     cull_backfaces=cull, mode=1)
         packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
         R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
-        params = F.mesh_params(V, size, 1, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip)
+        # z_clip = 0: the no-clipping rule on both sides, so that faces crossing the near region stay comparable bit for bit
+        params = F.mesh_params(V, size, 1, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip, z_clip=0.0)
         img, p2f = F.render_meshes_fragments(packed, R, T, _t([[0, 1, 0]]), params)
         p2f, img = p2f.cpu().numpy(), img.cpu().numpy()
         assert np.array_equal(p2f, want["pix_to_face"]), (seed, case, int((p2f != want["pix_to_face"]).sum()))
@@ -958,7 +959,7 @@ def test_mesh_backward_random_configurations(oracle, seed):
     el = rng.uniform(-75, 75, (B, V)).astype(np.float32)
     di = rng.uniform(1.3, 3.0, (B, V)).astype(np.float32)
     r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white",
-                   light_direction="relative" if relative else "fixed", perspective_correct=persp).eval()
+                   light_direction="relative" if relative else "fixed", perspective_correct=persp, z_clip=0.0).eval()
     leaves = [_t(x).requires_grad_(True) for x in (az, el, di)]
     images, _ = r([Meshes([v], [f]) for v, f in zip(vl, fl)], None, *leaves)
     ldir = oracle.camera_position(az, el, di) if relative else np.array([[0.0, 1.0, 0.0]], np.float32)
@@ -1179,3 +1180,54 @@ def test_custom_vertex_colours_with_a_packed_batch(oracle):
     want = oracle.render_meshes(vl, fl, az, el, di, size, vert_colors=vc, bg_color=(0.99999,) * 3)
     assert np.abs(img_packed.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
     assert float((img_packed - 0.99999).abs().max()) > 0.05      # not a white render
+
+
+def test_z_clip_culls_like_the_reference_and_counts_straddling_faces(oracle):
+    """PyTorch3D >= 0.5 clips faces at view depth znear / 2 = 0.5 (SURVEY A.9 ii; active as soon as transform_distance
+    lets dist drop towards 1.1, models/mvtn.py:33,68,109).  The library applies the cull half of that rule exactly
+    (faces wholly nearer than the plane disappear) and counts the faces that straddle the plane, which it rasterises
+    whole: (a) at dist 2.2 nothing straddles and the images ARE the clipping reference's; (b) at dist 1.1 the image is
+    bit-exactly "oracle without clipping on the mesh minus the wholly-near faces", and the straddler count equals the
+    oracle's; (c) z_clip = 0 switches the rule off."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = _mesh_batch([("M", 0), ("S", 4)])
+    B, V, size = 2, 4, 96
+    az, el, _ = _views(B, 4, 3)
+    obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
+    light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    for dist, expect_straddlers in ((2.2, False), (1.1, True)):
+        di = np.full((B, V), dist, np.float32)
+        R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+        params = F.mesh_params(V, size, 1, obj, bg)                       # z_clip = None -> 0.5 (perspective_correct)
+        assert abs(params.z_clip - 0.5) < 1e-12
+        img, p2f, ns = F.render_meshes_fragments(packed, R, T, light, params, return_straddlers=True)
+        clipref = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, z_clip=0.5)
+        assert int(ns.item()) == int(clipref["straddlers"].sum())
+        assert (int(ns.item()) > 0) == expect_straddlers
+        p2f, img = p2f.cpu().numpy(), img.cpu().numpy()
+        if not expect_straddlers:
+            assert np.array_equal(p2f, clipref["pix_to_face"]) and np.abs(img - clipref["images"]).max() <= TOL_PIXEL
+            continue
+        # expected images: per view, the no-clipping render of the mesh without the faces wholly nearer than the plane
+        Ro, To = oracle.look_at(az, el, di)
+        n_culled = 0
+        for b in range(B):
+            for v in range(V):
+                n = b * V + v
+                zv = (vl[b].astype(np.float32) @ Ro[n] + To[n])[:, 2]
+                keep = ~(zv[fl[b]] < np.float32(0.5)).all(1)
+                n_culled += int((~keep).sum())
+                idx = np.nonzero(keep)[0]
+                w = oracle.render_meshes([vl[b]], [fl[b][keep]], az[b:b + 1, v:v + 1], el[b:b + 1, v:v + 1], di[b:b + 1, v:v + 1],
+                                         size, obj_color=obj, bg_color=bg, z_clip=0.0)
+                # vertex normals are a property of the WHOLE mesh: compare coverage only (faces renumbered back)
+                wp = w["pix_to_face"][0]
+                wp = np.where(wp >= 0, idx[np.maximum(wp, 0)], -1)
+                assert np.array_equal(p2f[n], wp), (dist, n, int((p2f[n] != wp).sum()))
+        assert n_culled > 0
+        off = F.mesh_params(V, size, 1, obj, bg, z_clip=0.0)
+        img0, p2f0, ns0 = F.render_meshes_fragments(packed, R, T, light, off, return_straddlers=True)
+        legacy = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, z_clip=0.0)
+        assert int(ns0.item()) == 0 and np.array_equal(p2f0.cpu().numpy(), legacy["pix_to_face"])

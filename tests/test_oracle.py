@@ -271,3 +271,70 @@ def test_points_topk(oracle):
     ok = cov & (w > 1e-3)
     img = c["images"].reshape(2, 3, 64, 64)
     assert np.abs(img[:, 0][ok] - 0.3).max() < 1e-5 and np.abs(img[:, 2][ok] - 0.9).max() < 1e-5
+
+
+def _ray_triangle(px, py, s, V):
+    """Analytic hit of the pixel ray (view space, camera at the origin) with the plane of triangle V (3,3):
+    returns (z, barycentrics) in float64."""
+    d = np.array([px / s, py / s, 1.0])          # point on the ray at depth z is z * d
+    n = np.cross(V[1] - V[0], V[2] - V[0])
+    z = (n @ V[0]) / (n @ d)
+    P = z * d
+    T = np.stack([V[0] - V[2], V[1] - V[2]], 1)
+    l01 = np.linalg.lstsq(T, P - V[2], rcond=None)[0]
+    return z, np.array([l01[0], l01[1], 1 - l01.sum()])
+
+
+@pytest.mark.parametrize("behind", [1, 2])
+def test_ka11_z_clip_of_a_straddling_face(oracle, behind):
+    """KA11 (SURVEY A.9 ii): PyTorch3D >= 0.5 clips faces at z = znear / 2 = 0.5.  One triangle with `behind` vertices
+    nearer than the plane, identity camera: the drawn region is exactly {pixels whose ray hits the triangle at depth
+    >= 0.5}; depth and the barycentrics (mapped back to the ORIGINAL triangle) equal the analytic ray hit — clipping in
+    x*z / y*z is geometrically exact.  Without z_clip the face is drawn whole (0.4-style behaviour)."""
+    V = np.array([[-0.30, -0.20, 0.25], [0.35, -0.25, 1.5], [0.05, 0.30, 1.2]], np.float64)
+    if behind == 2:
+        V[2, 2] = 0.4
+    f = np.array([[0, 1, 2]], np.int64)
+    S = 64
+    R, T = np.eye(3)[None], np.zeros((1, 3))
+    kw = dict(image_size=S, R=R, T=T, dtype=np.float64, obj_color=(1, 1, 1), bg_color=(0, 0, 0))
+    one = np.zeros((1, 1))
+    out = oracle.render_meshes([V], [f], one, one, one + 1, z_clip=0.5, **kw)
+    full = oracle.render_meshes([V], [f], one, one, one + 1, z_clip=0.0, **kw)
+    assert out["straddlers"][0] == 1 and full["straddlers"][0] == 0
+    s = 1.0 / np.tan(np.radians(30.0))
+    cov, covfull = out["pix_to_face"][0] >= 0, full["pix_to_face"][0] >= 0
+    assert covfull.sum() > cov.sum() > 20 and not (cov & ~covfull).any()
+    n_checked = 0
+    for yi in range(S):
+        for xi in range(S):
+            px, py = 1 - (2 * xi + 1) / S, 1 - (2 * yi + 1) / S
+            z, b = _ray_triangle(px, py, s, V)
+            inside = (b > 1e-9).all()
+            near_edge = (np.abs(b) < 1e-6).any() or abs(z - 0.5) < 1e-6
+            if near_edge:
+                continue
+            assert covfull[yi, xi] == inside
+            assert cov[yi, xi] == (inside and z >= 0.5), (xi, yi, z, b)
+            if cov[yi, xi]:
+                n_checked += 1
+                assert abs(out["zbuf"][0, yi, xi] - z) < 1e-9
+                assert np.abs(out["bary"][0, yi, xi] - b).max() < 1e-9
+    assert n_checked > 20
+    # float32 instance: same coverage away from the edges
+    out32 = oracle.render_meshes([V.astype(np.float32)], [f], one, one, one + 1, z_clip=0.5,
+                                 **dict(kw, dtype=np.float32, R=R.astype(np.float32), T=T.astype(np.float32)))
+    assert (out32["pix_to_face"][0] >= 0).sum() == cov.sum()
+
+
+def test_ka12_z_clip_culls_faces_wholly_behind_the_plane(oracle):
+    """All three vertices nearer than z_clip: culled; the literal loop (mode 0) and the face-major loop (mode 1) agree."""
+    V = np.array([[-0.1, -0.1, 0.3], [0.1, -0.1, 0.4], [0.0, 0.1, 0.45], [-0.5, -0.5, 2.0], [0.5, -0.5, 2.0], [0.0, 0.5, 2.0]])
+    f = np.array([[0, 1, 2], [3, 4, 5]], np.int64)
+    kw = dict(image_size=32, R=np.eye(3)[None], T=np.zeros((1, 3)), dtype=np.float64)
+    one = np.zeros((1, 1))
+    a = oracle.render_meshes([V], [f], one, one, one + 1, z_clip=0.5, **kw)
+    b = oracle.render_meshes([V], [f], one, one, one + 1, z_clip=0.0, **kw)
+    assert not (a["pix_to_face"] == 0).any() and (b["pix_to_face"] == 0).any() and (a["pix_to_face"] == 1).any()
+    c = oracle.render_meshes([V], [f], one, one, one + 1, z_clip=0.5, mode=0, **kw)
+    assert np.array_equal(a["pix_to_face"], c["pix_to_face"]) and np.array_equal(a["images"], c["images"])
