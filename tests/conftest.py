@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:   # shared test helpers (reg_composition.py, hostmath.py)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def pytest_configure(config):

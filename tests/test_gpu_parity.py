@@ -678,26 +678,7 @@ def test_edge_case_points_ragged_counts(oracle):
         assert np.abs(img.cpu().numpy() - want["images"]).max() <= 1e-6
 
 
-def _regularize_composition(x, p, augment, crop_ratio):
-    """What ops.py:168-176 does, spelled with plain torch ops (dropout over whole views; per image of the view-major
-    flattened batch: masked column flip, replicate padding, window gather), drawing from the generators in that order."""
-    import warnings
-    from mvtn_amd.helpers import batch_tensor, unbatch_tensor
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        x = torch.nn.functional.dropout2d(x, p=p, training=True)
-    if not augment:
-        return x
-    B, V, C, H, W = x.shape
-    flat = batch_tensor(x, dim=1, squeeze=True)
-    pad = int((1 + crop_ratio) * H) - H
-    flipped = (torch.rand(flat.shape[0]) < 0.5).to(x.device)
-    flat = torch.where(flipped[:, None, None, None], torch.flip(flat, [3]), flat)
-    padded = torch.nn.ReplicationPad2d(pad)(flat)
-    i = torch.randint(0, 2 * pad + 1, (flat.shape[0],))
-    j = torch.randint(0, 2 * pad + 1, (flat.shape[0],))
-    out = torch.stack([padded[m, :, int(i[m]):int(i[m]) + H, int(j[m]):int(j[m]) + H] for m in range(flat.shape[0])])
-    return unbatch_tensor(out, dim=1, unsqueeze=True, batch_size=B)
+from reg_composition import regularize_composition as _regularize_composition  # noqa: E402  (tests/reg_composition.py)
 
 
 @pytest.mark.parametrize("B,V,C,H,p,augment,crop_ratio", [
@@ -1231,3 +1212,45 @@ def test_z_clip_culls_like_the_reference_and_counts_straddling_faces(oracle):
         img0, p2f0, ns0 = F.render_meshes_fragments(packed, R, T, light, off, return_straddlers=True)
         legacy = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, z_clip=0.0)
         assert int(ns0.item()) == 0 and np.array_equal(p2f0.cpu().numpy(), legacy["pix_to_face"])
+
+
+def test_regularize_views_reproduces_the_reference_fixture():
+    """tests/golden/regularize_views.npz was written by the REFERENCE's regualarize_rendered_views (ops.py:168-176) on the
+    CPU; with dropout off every draw comes from the CPU generator, so the product (fused HIP pass, draws re-indexed from
+    the reference's view-major order) must reproduce those outputs bit for bit under the same seed."""
+    import os
+    from mvtn_amd import regularize as rg
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "regularize_views.npz"))
+    n = 0
+    for name in fx["names"]:
+        B, V, C, H, p, aug, cr, seed = fx["cfg_" + str(name)]
+        if p > 0:
+            continue      # the keep mask is drawn on the GPU generator in the product (on the CPU in the fixture)
+        x = torch.from_numpy(fx["x_" + str(name)]).to(_dev())
+        torch.manual_seed(int(seed))
+        got = rg.regualarize_rendered_views(x, float(p), bool(aug), float(cr))
+        assert np.array_equal(got.cpu().numpy(), fx["y_" + str(name)]), name
+        n += 1
+    assert n >= 2
+
+
+def test_hip_path_against_the_torch_restatement_of_c1():
+    """The HIP path against the second, torch-made implementation of BASELINE configs[0] directly (no C oracle in between;
+    tests/golden/torch_restatement_c1.npz): pixel -> face identical up to a handful of edge pixels, colours within 1e-4."""
+    import os
+    from mvtn_amd import MVRenderer, Meshes, functional as F
+    from mvtn_amd.structures import PackedMeshes
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "torch_restatement_c1.npz"))
+    v, f = syn.synthetic_mesh(str(fx["mesh"][0]), int(fx["mesh"][1]))
+    S, V = int(fx["image_size"]), 4
+    packed = PackedMeshes.from_meshes(Meshes([v], [f]), _dev())
+    R, T = F.look_at_view_transform(_t(fx["dist"]), _t(fx["elev"]), _t(fx["azim"]))
+    assert np.abs(R.cpu().numpy() - fx["R"]).max() <= 2.5e-7
+    params = F.mesh_params(V, S, 1, (0.99999,) * 3, (0.99999,) * 3)
+    img, p2f = F.render_meshes_fragments(packed, R, T, _t(np.array([[0.0, 1.0, 0.0]], np.float32)), params)
+    differ = p2f.cpu().numpy() != fx["pix_to_face"].astype(np.int32)
+    assert differ.sum() <= 8
+    assert np.abs(img.cpu().numpy()[0] - fx["images"]).max(1)[~differ].max() <= TOL_PIXEL
+    r = MVRenderer(V, S, pc_rendering=False, light_direction="fixed").eval()
+    img2, _ = r([Meshes([v], [f])], None, _t(fx["azim"][None]), _t(fx["elev"][None]), _t(fx["dist"][None]))
+    assert torch.equal(img2, img)

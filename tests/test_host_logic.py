@@ -329,3 +329,19 @@ def test_regularize_c_abi_argument_validation_without_gpu():
     assert lib.mvr_regularize_views_forward(a, 1, 1, 4, 4, None, None, a, None, 1, o, None) == 1            # crop_i without crop_j
     assert lib.mvr_regularize_views_backward(a, 1, 1, 4, 4, None, None, None, None, -1, o, None) == 1
     assert b"mvr_regularize_views" in lib.mvr_last_error()
+
+
+def test_regularize_composition_is_pinned_to_the_reference():
+    """The torch composition the GPU test compares the fused regulariser against (tests/reg_composition.py) reproduces,
+    bit for bit and under the same seeds, what the REFERENCE's regualarize_rendered_views returned on the CPU
+    (tests/golden/make_regularize_golden.py ran ops.py:168-176 itself): dropout mask, flips, replicate padding, windows
+    and the view-major flattening of super_batched_op."""
+    from reg_composition import regularize_composition
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "regularize_views.npz"))
+    assert len(fx["names"]) >= 5
+    for name in fx["names"]:
+        B, V, C, H, p, aug, cr, seed = fx["cfg_" + str(name)]
+        x = torch.from_numpy(fx["x_" + str(name)])
+        torch.manual_seed(int(seed))
+        got = regularize_composition(x, float(p), bool(aug), float(cr))
+        assert np.array_equal(got.numpy(), fx["y_" + str(name)]), name
