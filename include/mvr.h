@@ -297,6 +297,21 @@ int mvr_regularize_views_backward(const float *grad_out, int32_t n_images, int32
                                   const float *scale, const uint8_t *flip, const int32_t *crop_i,
                                   const int32_t *crop_j, int32_t pad, float *grad_images, mvr_stream_t stream);
 
+/* The same pass with the per-channel `Normalize` of the reference's trainer fused behind it
+ * (viewGCN/tools/Trainer_mvt.py:41-49: (x - 0.456) / 0.225 on every channel, applied right after `mvctosvc`, ops.py:283,
+ * which is a pure reshape of the contiguous (B, V, C, H, W) block to (B V, C, H, W) and costs nothing here):
+ *   out = (regularised - mean[c]) / std[c]      (true division: the bits of the torch expression)
+ * mean, std: `channels` (<= 4) HOST floats each, or both NULL.  scale / flip / crop_i / crop_j may all be NULL: then
+ * this is the stand-alone Normalize (one read + one write of every frame). */
+int mvr_regularize_normalize_views_forward(const float *images, int32_t n_images, int32_t channels, int32_t h, int32_t w,
+                                           const float *scale, const uint8_t *flip, const int32_t *crop_i,
+                                           const int32_t *crop_j, int32_t pad, const float *mean, const float *std_,
+                                           float *out, mvr_stream_t stream);
+int mvr_regularize_normalize_views_backward(const float *grad_out, int32_t n_images, int32_t channels, int32_t h, int32_t w,
+                                            const float *scale, const uint8_t *flip, const int32_t *crop_i,
+                                            const int32_t *crop_j, int32_t pad, const float *mean, const float *std_,
+                                            float *grad_images, mvr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,8 @@ _PL = ctypes.POINTER(PackLayout)
 PROTOTYPES = {
     "mvr_regularize_views_forward": (ctypes.c_int, [_vp] + [ctypes.c_int32] * 4 + [_vp] * 4 + [ctypes.c_int32, _vp, _vp]),
     "mvr_regularize_views_backward": (ctypes.c_int, [_vp] + [ctypes.c_int32] * 4 + [_vp] * 4 + [ctypes.c_int32, _vp, _vp]),
+    "mvr_regularize_normalize_views_forward": (ctypes.c_int, [_vp] + [ctypes.c_int32] * 4 + [_vp] * 4 + [ctypes.c_int32, c_float_p, c_float_p, _vp, _vp]),
+    "mvr_regularize_normalize_views_backward": (ctypes.c_int, [_vp] + [ctypes.c_int32] * 4 + [_vp] * 4 + [ctypes.c_int32, c_float_p, c_float_p, _vp, _vp]),
     "mvr_pack_meshes_layout": (ctypes.c_int, [ctypes.c_int32, _vp, _vp, _PL]),
     "mvr_pack_meshes_host": (ctypes.c_int, [_PL, _vp, _vp, _vp, _vp, _vp]),
     "mvr_version": (ctypes.c_int, []),

@@ -24,6 +24,11 @@ struct RegArgs {
   const int32_t *crop_j;   // (N) column offset
   int32_t pad, C, H, W;
   int64_t rows;            // N * C * H
+  // optional per-channel normalisation fused behind the regulariser: out = (regularised - mean[c]) / std[c] — the
+  // `Normalize` of the reference's trainer (viewGCN/tools/Trainer_mvt.py:41-49: ImageNet mean 0.456, std 0.225), which
+  // otherwise is two more full-frame passes.  The quotient is a true division: bit-identical to the torch expression.
+  int32_t norm;
+  float mean[4], stdv[4];
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -56,6 +61,12 @@ __global__ __launch_bounds__(kBlock) void k_regularize_views_fwd(const float *__
       const float x = src[sx];
       v[k] = a.scale ? x * s : x;
     }
+  }
+  if (a.norm) {
+    const int c = (int)(nc % a.C);
+    const float m = a.mean[c], sd = a.stdv[c];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = (v[k] - m) / sd;
   }
   float *dst = out + row * a.W + xg * VEC;
   if constexpr (VEC == 4) {
@@ -98,6 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_regularize_views_bwd(const float *__
     int ilo, ihi;
     preimage(y, a.crop_i ? a.crop_i[n] - a.pad : 0, a.H, ilo, ihi);
     const float *src = gout + nc * a.H * a.W;
+    const float sd = a.norm ? a.stdv[(int)(nc % a.C)] : 1.0f;
     int jc[VEC];
     bool in[VEC];
 #pragma unroll
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_regularize_views_bwd(const float *__
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) t[r][k] = src[(int64_t)(i + r) * a.W + jc[k]];
+        for (int k = 0; k < VEC; ++k) { t[r][k] = src[(int64_t)(i + r) * a.W + jc[k]]; if (a.norm) t[r][k] = t[r][k] / sd; }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_regularize_views_bwd(const float *__
     for (; i <= ihi; ++i) {                   // every other source row has one reader row (or none)
       float t[VEC];
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) t[k] = src[(int64_t)i * a.W + jc[k]];
+      for (int k = 0; k < VEC; ++k) { t[k] = src[(int64_t)i * a.W + jc[k]]; if (a.norm) t[k] = t[k] / sd; }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) v[k] += in[k] ? t[k] : 0.0f;
     }
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_regularize_views_bwd(const float *__
 }
 
 // sum of p[0 .. nj) by 16 lanes, 8 loads in flight per lane, fixed order
-__device__ __forceinline__ float row_sum16(const float *__restrict__ p, int nj, int lane) {
+__device__ __forceinline__ float row_sum16(const float *__restrict__ p, int nj, int lane, bool norm, float sd) {
   float t = 0.0f;
   for (int e0 = 0; e0 < nj; e0 += 128) {
     float u[8];
@@ -149,6 +161,7 @@ __device__ __forceinline__ float row_sum16(const float *__restrict__ p, int nj, 
     for (int k = 0; k < 8; ++k) {
       const int e = e0 + lane + 16 * k;
       u[k] = e < nj ? p[e] : 0.0f;
+      if (norm) u[k] = u[k] / sd;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += u[k];
@@ -182,6 +195,8 @@ __global__ __launch_bounds__(kBlock) void k_regularize_views_bwd_columns(const f
   const int nj = jhi - jlo + 1;
   const float *src = gout + nc * a.H * a.W + jlo;
   const bool f = a.flip && a.flip[n];
+  const bool nrm = a.norm != 0;
+  const float sd = nrm ? a.stdv[(int)(nc % a.C)] : 1.0f;
   float *dst = gin + nc * a.H * a.W + (f ? a.W - 1 - xs : xs);
   const int y = y0 + grp;
   if (y < a.H) {                            // source rows with at most one reader row
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_regularize_views_bwd_columns(const f
     preimage(y, oi, a.H, ilo, ihi);
     if (ihi <= ilo) {
       float acc = 0.0f;
-      if (!dropped && ihi == ilo && nj > 0) acc = row_sum16(src + (int64_t)ilo * a.W, nj, lane);
+      if (!dropped && ihi == ilo && nj > 0) acc = row_sum16(src + (int64_t)ilo * a.W, nj, lane, nrm, sd);
       acc = reduce16(acc);
       if (lane == 0) dst[(int64_t)y * a.W] = a.scale ? acc * s : acc;
     }
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_regularize_views_bwd_columns(const f
     if (ihi <= ilo) continue;
     float acc = 0.0f;
     if (!dropped && nj > 0)
-      for (int i = ilo + grp; i <= ihi; i += 16) acc += row_sum16(src + (int64_t)i * a.W, nj, lane);
+      for (int i = ilo + grp; i <= ihi; i += 16) acc += row_sum16(src + (int64_t)i * a.W, nj, lane, nrm, sd);
     acc = reduce16(acc);
     if (lane == 0) s_red[grp] = acc;
     __syncthreads();
@@ -233,8 +248,46 @@ int fill_args(RegArgs &a, int32_t n_images, int32_t channels, int32_t h, int32_t
               const int32_t *crop_i, const int32_t *crop_j, int32_t pad) {
   if (n_images <= 0 || channels <= 0 || h <= 0 || w <= 0) return bad("mvr_regularize_views: bad image shape");
   if (pad < 0 || ((crop_i == nullptr) != (crop_j == nullptr))) return bad("mvr_regularize_views: crop_i and crop_j go together, pad >= 0");
-  a = RegArgs{scale, flip, crop_i, crop_j, pad, channels, h, w, (int64_t)n_images * channels * h};
+  a = RegArgs{scale, flip, crop_i, crop_j, pad, channels, h, w, (int64_t)n_images * channels * h, 0, {0, 0, 0, 0}, {1, 1, 1, 1}};
   return MVR_OK;
+}
+
+int fill_norm(RegArgs &a, const float *mean, const float *stdv) {
+  if (!mean && !stdv) return MVR_OK;
+  if (!mean || !stdv) return bad("mvr_regularize_normalize_views: mean and std go together");
+  if (a.C > 4) return bad("mvr_regularize_normalize_views: at most 4 channels");
+  a.norm = 1;
+  for (int c = 0; c < a.C; ++c) {
+    if (!(stdv[c] != 0.0f)) return bad("mvr_regularize_normalize_views: std must be non-zero");
+    a.mean[c] = mean[c]; a.stdv[c] = stdv[c];
+  }
+  return MVR_OK;
+}
+
+int launch_fwd(const float *images, float *out, const RegArgs &a, mvr_stream_t stream) {
+  if (a.W % 4 == 0) {
+    const int64_t total = a.rows * (a.W / 4);
+    hipLaunchKernelGGL(k_regularize_views_fwd<4>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, images, out, a);
+  } else {
+    const int64_t total = a.rows * a.W;
+    hipLaunchKernelGGL(k_regularize_views_fwd<1>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, images, out, a);
+  }
+  return check(hipGetLastError(), "k_regularize_views_fwd");
+}
+
+int launch_bwd(const float *grad_out, float *grad_images, const RegArgs &a, int32_t n_images, mvr_stream_t stream) {
+  if (a.W % 4 == 0) {
+    const int64_t total = a.rows * (a.W / 4);
+    hipLaunchKernelGGL(k_regularize_views_bwd<4>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, grad_out, grad_images, a);
+  } else {
+    const int64_t total = a.rows * a.W;
+    hipLaunchKernelGGL(k_regularize_views_bwd<1>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, grad_out, grad_images, a);
+  }
+  if (int rc = check(hipGetLastError(), "k_regularize_views_bwd")) return rc;
+  if (!a.crop_j) return MVR_OK;   // no shift: every source pixel has exactly one reader, the kernel above is complete
+  const int64_t blocks = (int64_t)n_images * a.C * ((a.H + 15) / 16);
+  hipLaunchKernelGGL(k_regularize_views_bwd_columns, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, grad_out, grad_images, a);
+  return check(hipGetLastError(), "k_regularize_views_bwd_columns");
 }
 
 }  // namespace
@@ -245,14 +298,7 @@ extern "C" int mvr_regularize_views_forward(const float *images, int32_t n_image
   RegArgs a;
   if (!images || !out || images == out) return bad("mvr_regularize_views_forward: images and out must be distinct buffers");
   if (int rc = fill_args(a, n_images, channels, h, w, scale, flip, crop_i, crop_j, pad)) return rc;
-  if (w % 4 == 0) {
-    const int64_t total = a.rows * (w / 4);
-    hipLaunchKernelGGL(k_regularize_views_fwd<4>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, images, out, a);
-  } else {
-    const int64_t total = a.rows * w;
-    hipLaunchKernelGGL(k_regularize_views_fwd<1>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, images, out, a);
-  }
-  return check(hipGetLastError(), "k_regularize_views_fwd");
+  return launch_fwd(images, out, a, stream);
 }
 
 extern "C" int mvr_regularize_views_backward(const float *grad_out, int32_t n_images, int32_t channels, int32_t h, int32_t w,
@@ -261,16 +307,30 @@ extern "C" int mvr_regularize_views_backward(const float *grad_out, int32_t n_im
   RegArgs a;
   if (!grad_out || !grad_images || grad_out == grad_images) return bad("mvr_regularize_views_backward: grad_out and grad_images must be distinct buffers");
   if (int rc = fill_args(a, n_images, channels, h, w, scale, flip, crop_i, crop_j, pad)) return rc;
-  if (w % 4 == 0) {
-    const int64_t total = a.rows * (w / 4);
-    hipLaunchKernelGGL(k_regularize_views_bwd<4>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, grad_out, grad_images, a);
-  } else {
-    const int64_t total = a.rows * w;
-    hipLaunchKernelGGL(k_regularize_views_bwd<1>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, grad_out, grad_images, a);
-  }
-  if (int rc = check(hipGetLastError(), "k_regularize_views_bwd")) return rc;
-  if (!crop_j) return MVR_OK;   // no shift: every source pixel has exactly one reader, the kernel above is complete
-  const int64_t blocks = (int64_t)n_images * channels * ((h + 15) / 16);
-  hipLaunchKernelGGL(k_regularize_views_bwd_columns, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, grad_out, grad_images, a);
-  return check(hipGetLastError(), "k_regularize_views_bwd_columns");
+  return launch_bwd(grad_out, grad_images, a, n_images, stream);
+}
+
+// The same pass with the trainer's per-channel `Normalize` fused behind it: out = (regularised - mean[c]) / std[c];
+// mean / std: `channels` HOST floats each (both NULL: no normalisation).  Any of scale / flip / crop may be NULL, so this
+// is also the stand-alone Normalize.
+extern "C" int mvr_regularize_normalize_views_forward(const float *images, int32_t n_images, int32_t channels, int32_t h, int32_t w,
+                                                      const float *scale, const uint8_t *flip, const int32_t *crop_i,
+                                                      const int32_t *crop_j, int32_t pad, const float *mean, const float *stdv,
+                                                      float *out, mvr_stream_t stream) {
+  RegArgs a;
+  if (!images || !out || images == out) return bad("mvr_regularize_normalize_views_forward: images and out must be distinct buffers");
+  if (int rc = fill_args(a, n_images, channels, h, w, scale, flip, crop_i, crop_j, pad)) return rc;
+  if (int rc = fill_norm(a, mean, stdv)) return rc;
+  return launch_fwd(images, out, a, stream);
+}
+
+extern "C" int mvr_regularize_normalize_views_backward(const float *grad_out, int32_t n_images, int32_t channels, int32_t h, int32_t w,
+                                                       const float *scale, const uint8_t *flip, const int32_t *crop_i,
+                                                       const int32_t *crop_j, int32_t pad, const float *mean, const float *stdv,
+                                                       float *grad_images, mvr_stream_t stream) {
+  RegArgs a;
+  if (!grad_out || !grad_images || grad_out == grad_images) return bad("mvr_regularize_normalize_views_backward: grad_out and grad_images must be distinct buffers");
+  if (int rc = fill_args(a, n_images, channels, h, w, scale, flip, crop_i, crop_j, pad)) return rc;
+  if (int rc = fill_norm(a, mean, stdv)) return rc;
+  return launch_bwd(grad_out, grad_images, a, n_images, stream);
 }

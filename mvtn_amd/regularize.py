@@ -43,37 +43,90 @@ def draw_regularization(batch, nb_views, image_size, device, dropout_p=0.0, augm
     return scale, flip, ci, cj, pad
 
 
+def _cfloats(vals, n):
+    import ctypes
+    if vals is None:
+        return None
+    vals = [float(v) for v in vals]
+    if len(vals) == 1:
+        vals = vals * n
+    if len(vals) != n:
+        raise ValueError("mean / std need one value per channel (%d)" % n)
+    return (ctypes.c_float * n)(*vals)
+
+
 class _RegularizeViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, images, scale, flip, ci, cj, pad):
+    def forward(ctx, images, scale, flip, ci, cj, pad, mean=None, std=None):
         x = _f32c(images)
         _require_cuda(x, scale, flip, ci, cj)
         n, (c, h, w) = x.numel() // (x.shape[-3] * x.shape[-2] * x.shape[-1]), x.shape[-3:]
         out = torch.empty_like(x)
-        _lib.check(_lib.load().mvr_regularize_views_forward(x.data_ptr(), n, c, h, w, _p(scale), _p(flip), _p(ci), _p(cj), int(pad),
-                                                            out.data_ptr(), _stream()), "mvr_regularize_views_forward")
-        ctx.draws = (scale, flip, ci, cj, int(pad), n, c, h, w)
+        cm, cs = _cfloats(mean, c), _cfloats(std, c)
+        if cm is None:
+            _lib.check(_lib.load().mvr_regularize_views_forward(x.data_ptr(), n, c, h, w, _p(scale), _p(flip), _p(ci), _p(cj), int(pad),
+                                                                out.data_ptr(), _stream()), "mvr_regularize_views_forward")
+        else:
+            _lib.check(_lib.load().mvr_regularize_normalize_views_forward(x.data_ptr(), n, c, h, w, _p(scale), _p(flip), _p(ci), _p(cj),
+                                                                          int(pad), cm, cs, out.data_ptr(), _stream()),
+                       "mvr_regularize_normalize_views_forward")
+        ctx.draws = (scale, flip, ci, cj, int(pad), n, c, h, w, cm, cs)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        scale, flip, ci, cj, pad, n, c, h, w = ctx.draws
+        scale, flip, ci, cj, pad, n, c, h, w, cm, cs = ctx.draws
         g = _f32c(grad_out)
         gin = torch.empty_like(g)
-        _lib.check(_lib.load().mvr_regularize_views_backward(g.data_ptr(), n, c, h, w, _p(scale), _p(flip), _p(ci), _p(cj), pad,
-                                                             gin.data_ptr(), _stream()), "mvr_regularize_views_backward")
-        return gin, None, None, None, None, None
+        if cm is None:
+            _lib.check(_lib.load().mvr_regularize_views_backward(g.data_ptr(), n, c, h, w, _p(scale), _p(flip), _p(ci), _p(cj), pad,
+                                                                 gin.data_ptr(), _stream()), "mvr_regularize_views_backward")
+        else:
+            _lib.check(_lib.load().mvr_regularize_normalize_views_backward(g.data_ptr(), n, c, h, w, _p(scale), _p(flip), _p(ci), _p(cj),
+                                                                           pad, cm, cs, gin.data_ptr(), _stream()),
+                       "mvr_regularize_normalize_views_backward")
+        return gin, None, None, None, None, None, None, None
 
 
 def _p(t):
     return None if t is None else t.data_ptr()
 
 
-def apply_regularization(rendered_images, scale=None, flip=None, crop_i=None, crop_j=None, pad=0):
-    """Apply given draws (see `draw_regularization`) to (..., C, H, W) images; differentiable w.r.t. the images."""
-    if scale is None and flip is None and crop_i is None:
+def apply_regularization(rendered_images, scale=None, flip=None, crop_i=None, crop_j=None, pad=0, mean=None, std=None):
+    """Apply given draws (see `draw_regularization`) to (..., C, H, W) images; differentiable w.r.t. the images.
+    `mean` / `std` (per channel, or one value for all): the fused `(x - mean) / std` of `normalize_views`."""
+    if scale is None and flip is None and crop_i is None and mean is None:
         return rendered_images
-    return _RegularizeViews.apply(rendered_images, scale, flip, crop_i, crop_j, pad)
+    return _RegularizeViews.apply(rendered_images, scale, flip, crop_i, crop_j, pad, mean, std)
+
+
+IMAGENET_MEAN, IMAGENET_STD = (0.456, 0.456, 0.456), (0.225, 0.225, 0.225)   # viewGCN/tools/Trainer_mvt.py:45,47
+
+
+def mvctosvc(x):
+    """ops.py:283 rearrange(x, 'b m c h w -> (b m) c h w'): a view of the contiguous block the renderer returns."""
+    return x.reshape((x.shape[0] * x.shape[1],) + tuple(x.shape[2:]))
+
+
+def normalize_views(x, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """viewGCN/tools/Trainer_mvt.py:41-49 `Normalize`: (x - mean) / std per channel on (N, C, H, W) (or (B, V, C, H, W))
+    images, one fused pass; differentiable."""
+    return apply_regularization(x, mean=mean, std=std)
+
+
+def regularize_normalize_views(rendered_images, dropout_p=0, augment_training=False, crop_ratio=0.3,
+                               mean=IMAGENET_MEAN, std=IMAGENET_STD, flatten=True):
+    """The three steps between the renderer and the classifier in the reference's training loop as ONE pass over the
+    frames: regualarize_rendered_views (run_mvtn.py:186-187; ops.py:168-176) -> mvctosvc (run_mvtn.py:249; ops.py:283) ->
+    Normalize (viewGCN/tools/Trainer_mvt.py:41-49).  Returns (B V, C, H, W) (`flatten`) or (B, V, C, H, W)."""
+    if rendered_images.dim() != 5:
+        raise ValueError("expected (B, V, C, H, W) rendered images")
+    B, V, _, H, W = rendered_images.shape
+    if augment_training and H != W:
+        raise ValueError("applied_transforms crops to (H, H): square images only")
+    draws = draw_regularization(B, V, H, rendered_images.device, dropout_p, augment_training, crop_ratio)
+    out = apply_regularization(rendered_images, *draws, mean=mean, std=std)
+    return mvctosvc(out) if flatten else out
 
 
 def regualarize_rendered_views(rendered_images, dropout_p=0, augment_training=False, crop_ratio=0.3):

@@ -1254,3 +1254,64 @@ def test_hip_path_against_the_torch_restatement_of_c1():
     r = MVRenderer(V, S, pc_rendering=False, light_direction="fixed").eval()
     img2, _ = r([Meshes([v], [f])], None, _t(fx["azim"][None]), _t(fx["elev"][None]), _t(fx["dist"][None]))
     assert torch.equal(img2, img)
+
+
+@pytest.mark.parametrize("p,augment", [(0.3, True), (0.0, False), (0.5, False)])
+def test_regularize_normalize_views_fused_equals_chained(p, augment):
+    """Row f3, second half: regualarize_rendered_views -> mvctosvc (ops.py:283) -> Normalize
+    (viewGCN/tools/Trainer_mvt.py:41-49) as ONE pass: forward bit-identical to the three steps chained with torch ops on
+    the fused regulariser's output; gradients bit-identical on interior pixels, 1e-5 on the replicated border sums."""
+    from mvtn_amd import regularize as rg
+    dev = _dev()
+    B, V, C, H = 2, 3, 3, 64
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.rand(B, V, C, H, H, generator=g).to(dev)
+    G = torch.randn(B * V, C, H, H, generator=g).to(dev)
+    mean = torch.tensor(rg.IMAGENET_MEAN, device=dev).view(1, 3, 1, 1)
+    std = torch.tensor(rg.IMAGENET_STD, device=dev).view(1, 3, 1, 1)
+    xa = x0.clone().requires_grad_(True)
+    torch.manual_seed(3)
+    chained = (rg.mvctosvc(rg.regualarize_rendered_views(xa, p, augment, 0.3)) - mean) / std
+    chained.backward(G)
+    xb = x0.clone().requires_grad_(True)
+    torch.manual_seed(3)
+    fused = rg.regularize_normalize_views(xb, p, augment, 0.3)
+    assert fused.shape == (B * V, C, H, H) and torch.equal(fused, chained.detach())
+    fused.backward(G)
+    inner = (slice(None),) * 3 + (slice(1, H - 1), slice(1, H - 1))
+    assert torch.equal(xa.grad[inner], xb.grad[inner])
+    assert (xa.grad - xb.grad).abs().max().item() <= 1e-5 * max(1.0, xa.grad.abs().max().item())
+    # the stand-alone Normalize of the trainer
+    y = rg.normalize_views(rg.mvctosvc(x0))
+    assert torch.equal(y, (rg.mvctosvc(x0) - mean) / std)
+
+
+@pytest.mark.parametrize("cfg,V", [("circular", 4), ("spherical", 12), ("spherical", 20)])
+def test_view_selectors_on_the_device_feed_the_renderer(golden, cfg, V):
+    """Row f1: the non-learned selectors (models/mvtn.py:13-111) as device modules: `.cuda()` buffers, the reference's
+    (B, V) stride-(0, 1) expanded outputs with the golden values, consumed by MVRenderer without a copy to the host —
+    same images as handing contiguous tensors; with transform_distance the jitter is drawn on the device."""
+    from mvtn_amd import MVRenderer, Meshes
+    from mvtn_amd.views import view_selector
+    B, size = 3, 64
+    sel = view_selector(cfg, V, canonical_elevation=30.0, canonical_distance=2.2).to(_dev()).eval()
+    az, el, di = sel(None, c_batch_size=B)
+    g = golden["selectors"]["%s_%d" % (cfg, V)]
+    assert az.is_cuda and tuple(az.shape) == (B, V) and list(az.stride()) == g["stride"]
+    assert np.array_equal(az[0].cpu().numpy(), np.array(g["azim"], np.float32))
+    assert np.array_equal(el[0].cpu().numpy(), np.array(g["elev"], np.float32))
+    assert np.array_equal(di[1].cpu().numpy(), np.array(g["dist"], np.float32))
+    vl, fl = _mesh_batch([("S", 0), ("S", 1), ("S", 2)])
+    meshes = [Meshes([v], [f]) for v, f in zip(vl, fl)]
+    r = MVRenderer(V, size, pc_rendering=False, light_direction="relative").eval()
+    with torch.no_grad():
+        img, _ = r(meshes, None, az, el, di)
+        img2, _ = r(meshes, None, az.contiguous(), el.contiguous(), di.contiguous())
+    assert torch.equal(img, img2) and float((img - 0.99999).abs().max()) > 0.1
+    jit = view_selector(cfg, V, canonical_distance=2.2, transform_distance=True).to(_dev()).train()
+    torch.manual_seed(0)
+    _, _, dj = jit(None, c_batch_size=B)
+    assert dj.is_cuda and dj.is_contiguous() and float(dj.min()) >= 1.1 - 1e-6 and float(dj.max()) <= 3.3 + 1e-6 and float(dj.std()) > 0.1
+    with torch.no_grad():
+        imgj, _ = r(meshes, None, az, el, dj)      # distances down to 1.1: the z-clip cull may act, nothing may crash
+    assert torch.isfinite(imgj).all()
