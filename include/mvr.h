@@ -172,6 +172,33 @@ int mvr_pack_meshes_layout(int32_t n_meshes, const int32_t *n_verts, const int32
 int mvr_pack_meshes_host(const mvr_pack_layout *layout, const float *const *verts, const int32_t *n_verts,
                          const int64_t *const *faces, const int32_t *n_faces, void *block);
 
+/* ---- soft mesh path (models/renderer.py:3-12 imports SoftPhongShader / SoftSilhouetteShader; :42,:89-93 hold
+ * blur_radius / faces_per_pixel; the reference leaves them at 0 / 1 with the hard shader) --------------------------- */
+enum { MVR_SHADER_SOFT_PHONG = 0, MVR_SHADER_SOFT_SILHOUETTE = 1 };
+typedef struct mvr_soft_params {
+  float blur_radius;                 /* RasterizationSettings.blur_radius (squared NDC distance), >= 0 */
+  float sigma, gamma;                /* BlendParams (PyTorch3D defaults 1e-4, 1e-4) */
+  int32_t faces_per_pixel;           /* K in [1, 64] */
+  int32_t shader;                    /* MVR_SHADER_SOFT_PHONG: phong_shading of every fragment + softmax_rgb_blend;
+                                        MVR_SHADER_SOFT_SILHOUETTE: sigmoid_alpha_blend */
+  int32_t clip_barycentric_coords;   /* PyTorch3D: None -> True when blur_radius > 0 */
+} mvr_soft_params;
+
+size_t mvr_mesh_soft_workspace_bytes(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const mvr_soft_params *soft);
+
+/* images: (N, 4, H, W) RGBA planar (N = B V, n = b V + v; alpha = 1 - prod_k (1 - sigmoid(-dist_k / sigma)));
+ * pix_to_face: (N, H, W, K) LOCAL face indices of the K nearest candidate faces per pixel in ascending (z, face) order,
+ * -1 = none (required: the backward differentiates exactly these fragments). */
+int mvr_render_meshes_soft_forward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const mvr_soft_params *soft,
+                                   const float *R, const float *T, const float *light_dir, float *images, int32_t *pix_to_face,
+                                   void *workspace, size_t workspace_bytes, mvr_stream_t stream);
+/* grad_images: (N, 4, H, W).  The fragment selection is a constant; everything else (colours, depths in the softmax,
+ * signed distances in the coverage probabilities) is differentiated.  grad_light: (N, 3) or NULL. */
+int mvr_render_meshes_soft_backward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const mvr_soft_params *soft,
+                                    const float *R, const float *T, const float *light_dir, const int32_t *pix_to_face,
+                                    const float *grad_images, float *grad_R, float *grad_T, float *grad_light, void *workspace,
+                                    size_t workspace_bytes, mvr_stream_t stream);
+
 /* ---- mesh path: models/renderer.py:65-114 ------------------------------ */
 
 /* Scratch the mesh calls need (vertex attributes, projected vertices, backward partials). */

@@ -14,6 +14,7 @@ MVR_CULL_BACKFACES = 1
 MVR_PERSPECTIVE_CORRECT = 2
 MVR_WORKSPACE_FROM_FORWARD = 4
 MVR_RASTER_EXACT_ONLY = 8
+MVR_SHADER_SOFT_PHONG, MVR_SHADER_SOFT_SILHOUETTE = 0, 1
 
 
 class MeshBatch(ctypes.Structure):  # struct mvr_mesh_batch
@@ -28,6 +29,11 @@ class MeshParams(ctypes.Structure):  # struct mvr_mesh_params
                 ("fov_deg", ctypes.c_float), ("ambient", ctypes.c_float), ("diffuse", ctypes.c_float),
                 ("specular", ctypes.c_float), ("shininess", ctypes.c_float),
                 ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3), ("z_clip", ctypes.c_float)]
+
+
+class SoftParams(ctypes.Structure):  # struct mvr_soft_params
+    _fields_ = [("blur_radius", ctypes.c_float), ("sigma", ctypes.c_float), ("gamma", ctypes.c_float),
+                ("faces_per_pixel", ctypes.c_int32), ("shader", ctypes.c_int32), ("clip_barycentric_coords", ctypes.c_int32)]
 
 
 class PointsParams(ctypes.Structure):  # struct mvr_points_params
@@ -69,6 +75,9 @@ PROTOTYPES = {
     "mvr_camera_position": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp]),
     "mvr_camera_position_backward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "mvr_mesh_workspace_bytes": (ctypes.c_size_t, [_MB, _MP]),
+    "mvr_mesh_soft_workspace_bytes": (ctypes.c_size_t, [_MB, _MP, ctypes.POINTER(SoftParams)]),
+    "mvr_render_meshes_soft_forward": (ctypes.c_int, [_MB, _MP, ctypes.POINTER(SoftParams)] + [_vp] * 6 + [ctypes.c_size_t, _vp]),
+    "mvr_render_meshes_soft_backward": (ctypes.c_int, [_MB, _MP, ctypes.POINTER(SoftParams)] + [_vp] * 9 + [ctypes.c_size_t, _vp]),
     "mvr_mesh_clip_straddlers": (ctypes.c_int, [_MB, _MP, _vp, ctypes.c_size_t, _vp, _vp]),
     "mvr_mesh_redo_count": (ctypes.c_int, [_MB, _MP, _vp, ctypes.c_size_t, _vp, _vp]),
     "mvr_vertex_normals": (ctypes.c_int, [_MB, _vp, _vp, ctypes.c_size_t, _vp]),

@@ -530,6 +530,255 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
   acc[15] += g_l.x; acc[16] += g_l.y; acc[17] += g_l.z;
 }
 
+
+// ---- soft rasterisation (blur_radius > 0, faces_per_pixel = K) ------------------------------
+// PyTorch3D 0.7.x csrc/utils/geometry_utils.cuh + csrc/rasterize_meshes (CheckPixelInsideFace), recalled; the CPU
+// oracle restates the same operations independently (oracle/mvr_oracle_impl.inc, face_test_soft).
+
+// PointLineDistanceForward: squared distance from p to the SEGMENT a b; *t_out: the clamped parameter (or -1 when the
+// segment is degenerate and the distance is taken to b)
+template <typename T> MVR_HD T point_segment_dist2(T px, T py, T ax, T ay, T bx, T by, T *t_out = nullptr) {
+  const T bax = bx - ax, bay = by - ay;
+  const T l2 = bax * bax + bay * bay;
+  if (l2 <= (T)kEps) {
+    if (t_out) *t_out = (T)-1;
+    return (px - bx) * (px - bx) + (py - by) * (py - by);
+  }
+  T t = (bax * (px - ax) + bay * (py - ay)) / l2;
+  t = t < (T)0 ? (T)0 : (t > (T)1 ? (T)1 : t);
+  if (t_out) *t_out = t;
+  const T qx = ax + t * bax, qy = ay + t * bay;
+  return (px - qx) * (px - qx) + (py - qy) * (py - qy);
+}
+
+// PointTriangleDistanceForward: min over the edges (v0 v1), (v0 v2), (v1 v2); *edge: 0, 1, 2 in that order
+template <typename T> MVR_HD T point_triangle_dist2(T px, T py, const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, int *edge = nullptr,
+                                                    T *t_out = nullptr) {
+  T t01, t02, t12;
+  const T e01 = point_segment_dist2(px, py, v0.x, v0.y, v1.x, v1.y, &t01);
+  const T e02 = point_segment_dist2(px, py, v0.x, v0.y, v2.x, v2.y, &t02);
+  const T e12 = point_segment_dist2(px, py, v1.x, v1.y, v2.x, v2.y, &t12);
+  const int k = (e01 <= e02 && e01 <= e12) ? 0 : ((e02 <= e01 && e02 <= e12) ? 1 : 2);
+  if (edge) *edge = k;
+  if (t_out) *t_out = k == 0 ? t01 : (k == 1 ? t02 : t12);
+  return k == 0 ? e01 : (k == 1 ? e02 : e12);
+}
+
+template <typename T> struct SoftFrag {
+  T z, dist;          // interpolated depth (with the clipped barycentrics), SIGNED squared distance (negative inside)
+  T b0, b1, b2;       // barycentrics as stored in the fragments (clipped + renormalised when clip_bary)
+  T w0, w1, w2;       // (perspective-corrected) barycentrics before clipping
+  bool inside;
+};
+
+// The fragment of (pixel, face) without the acceptance tests.
+template <typename T> MVR_HD SoftFrag<T> soft_frag_eval(const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, T px, T py, bool persp, bool clip_bary) {
+  SoftFrag<T> f;
+  const T area = edge_fn(v2.x, v2.y, v0.x, v0.y, v1.x, v1.y) + (T)kEps;
+  T w0 = edge_fn(px, py, v1.x, v1.y, v2.x, v2.y) / area;
+  T w1 = edge_fn(px, py, v2.x, v2.y, v0.x, v0.y) / area;
+  T w2 = edge_fn(px, py, v0.x, v0.y, v1.x, v1.y) / area;
+  if (persp) {
+    const T t0 = (w0 * v1.z) * v2.z, t1 = (v0.z * w1) * v2.z, t2 = (v0.z * v1.z) * w2;
+    const T den = tmax((t0 + t1) + t2, (T)kEps);
+    w0 = t0 / den; w1 = t1 / den; w2 = t2 / den;
+  }
+  f.w0 = w0; f.w1 = w1; f.w2 = w2;
+  T c0 = w0, c1 = w1, c2 = w2;
+  if (clip_bary) {   // BarycentricClipForward
+    c0 = tmax(tmin(w0, (T)1), (T)0); c1 = tmax(tmin(w1, (T)1), (T)0); c2 = tmax(tmin(w2, (T)1), (T)0);
+    const T sm = tmax((c0 + c1) + c2, (T)1e-5);
+    c0 = c0 / sm; c1 = c1 / sm; c2 = c2 / sm;
+  }
+  f.b0 = c0; f.b1 = c1; f.b2 = c2;
+  f.z = (c0 * v0.z + c1 * v1.z) + c2 * v2.z;
+  f.inside = w0 > (T)0 && w1 > (T)0 && w2 > (T)0;
+  const T d = point_triangle_dist2(px, py, v0, v1, v2);
+  f.dist = f.inside ? -d : d;
+  return f;
+}
+
+// CheckPixelInsideFace with blur_radius > 0: true when the pixel is inside the face or nearer than sqrt(blur_radius).
+template <typename T> MVR_HD bool face_test_soft(const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, T px, T py, T blur_radius, T blur,
+                                                 bool persp, bool clip_bary, bool cull_backfaces, SoftFrag<T> *out) {
+  const T xmin = tmin(tmin(v0.x, v1.x), v2.x) - blur, xmax = tmax(tmax(v0.x, v1.x), v2.x) + blur;
+  const T ymin = tmin(tmin(v0.y, v1.y), v2.y) - blur, ymax = tmax(tmax(v0.y, v1.y), v2.y) + blur;
+  const T zmin = tmin(tmin(v0.z, v1.z), v2.z), zmax = tmax(tmax(v0.z, v1.z), v2.z);
+  const bool outside = px > xmax || px < xmin || py > ymax || py < ymin || zmin < (T)kEps;
+  const T face_area = edge_fn(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+  const bool zero_area = face_area <= (T)kEps && face_area >= -(T)kEps;
+  if (zmax < (T)0 || (cull_backfaces && face_area < (T)0) || outside || zero_area) return false;
+  const SoftFrag<T> f = soft_frag_eval(v0, v1, v2, px, py, persp, clip_bary);
+  if (f.z < (T)0) return false;
+  if (!f.inside && f.dist >= blur_radius) return false;
+  *out = f;
+  return true;
+}
+
+// Backward of one soft fragment: upstream gradients of its colour (gc), depth (gz) and signed distance (gd) ->
+// acc[18] (gR 9, gT 3, g camera centre 3, g light 3), like phong_pixel_bwd.  shade: 0 = Phong colour, 1 = texel only.
+template <typename T> MVR_HD void soft_fragment_bwd(const PixelGradIn<T> &cam, T px, T py, bool clip_bary, int shade,
+                                                    const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
+                                                    const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
+                                                    const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
+                                                    const V3<T> &G, T gzbuf, T gdist, T acc[18]) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+  // ---- forward recompute ---------------------------------------------------------------------------------------
+  const V3<T> Xv0 = world_to_view(cam.R, cam.Tr, X0), Xv1 = world_to_view(cam.R, cam.Tr, X1), Xv2 = world_to_view(cam.R, cam.Tr, X2);
+  const T rz0 = trcp(Xv0.z), rz1 = trcp(Xv1.z), rz2 = trcp(Xv2.z);
+  const T u0 = (cam.s * Xv0.x) * rz0, v0 = (cam.s * Xv0.y) * rz0, z0 = Xv0.z;
+  const T u1 = (cam.s * Xv1.x) * rz1, v1 = (cam.s * Xv1.y) * rz1, z1 = Xv1.z;
+  const T u2 = (cam.s * Xv2.x) * rz2, v2 = (cam.s * Xv2.y) * rz2, z2 = Xv2.z;
+  const T area = edge_fn(u2, v2, u0, v0, u1, v1) + (T)kEps;
+  const T ra = trcp(area);
+  const T e0 = edge_fn(px, py, u1, v1, u2, v2), e1 = edge_fn(px, py, u2, v2, u0, v0), e2 = edge_fn(px, py, u0, v0, u1, v1);
+  const T a0 = e0 * ra, a1 = e1 * ra, a2 = e2 * ra;
+  T w0 = a0, w1 = a1, w2 = a2, rden = (T)1;
+  bool den_clamped = false;
+  if (cam.persp) {
+    const T t0 = (a0 * z1) * z2, t1 = (z0 * a1) * z2, t2 = (z0 * z1) * a2;
+    const T sum = (t0 + t1) + t2;
+    rden = trcp(tmax(sum, (T)kEps));
+    den_clamped = !(sum > (T)kEps);
+    w0 = t0 * rden; w1 = t1 * rden; w2 = t2 * rden;
+  }
+  const bool inside = w0 > (T)0 && w1 > (T)0 && w2 > (T)0;
+  T x0 = w0, x1 = w1, x2 = w2, rS = (T)1;
+  bool s_clamped = false;
+  if (clip_bary) {
+    x0 = tmax(tmin(w0, (T)1), (T)0); x1 = tmax(tmin(w1, (T)1), (T)0); x2 = tmax(tmin(w2, (T)1), (T)0);
+    const T sm = (x0 + x1) + x2;
+    s_clamped = !(sm > (T)1e-5);
+    rS = trcp(tmax(sm, (T)1e-5));
+  }
+  const T b0 = x0 * rS, b1 = x1 * rS, b2 = x2 * rS;
+  // ---- colour backward -> gradients of the (clipped) barycentrics, of the camera centre and of the light --------------
+  T gb0, gb1, gb2;
+  V3<T> g_cc = {(T)0, (T)0, (T)0}, g_l = {(T)0, (T)0, (T)0};
+  if (shade == 0) {
+    const V3<T> p = {(b0 * X0.x + b1 * X1.x) + b2 * X2.x, (b0 * X0.y + b1 * X1.y) + b2 * X2.y, (b0 * X0.z + b1 * X1.z) + b2 * X2.z};
+    const V3<T> n = {(b0 * N0.x + b1 * N1.x) + b2 * N2.x, (b0 * N0.y + b1 * N1.y) + b2 * N2.y, (b0 * N0.z + b1 * N1.z) + b2 * N2.z};
+    const V3<T> tex = {(b0 * c0.x + b1 * c1.x) + b2 * c2.x, (b0 * c0.y + b1 * c1.y) + b2 * c2.y, (b0 * c0.z + b1 * c1.z) + b2 * c2.z};
+    T idn, idl, idv;
+    bool cn, cl, cv;
+    const V3<T> nh = normalize_rs(n, (T)kNormalizeEps, &idn, &cn);
+    V3<T> lh = cam.l;
+    idl = (T)1; cl = true;
+    if (!cam.l_is_unit) lh = normalize_rs(cam.l, (T)kNormalizeEps, &idl, &cl);
+    const T cosang = dot(nh, lh);
+    const bool lit = cosang > (T)0;
+    const V3<T> view = {cam.cc.x - p.x, cam.cc.y - p.y, cam.cc.z - p.z};
+    const V3<T> vh = normalize_rs(view, (T)kNormalizeEps, &idv, &cv);
+    const V3<T> refl = {-lh.x + (T)2 * (cosang * nh.x), -lh.y + (T)2 * (cosang * nh.y), -lh.z + (T)2 * (cosang * nh.z)};
+    const T dvr = dot(vh, refl);
+    const bool spec_on = lit && dvr > (T)0;
+    const T alpha = spec_on ? dvr : (T)0;
+    const T sc = cam.ph.ambient + cam.ph.diffuse * (lit ? cosang : (T)0);
+    const V3<T> g_tex = {G.x * sc, G.y * sc, G.z * sc};
+    const T g_sc = (G.x * tex.x + G.y * tex.y) + G.z * tex.z;
+    T g_cos = lit ? cam.ph.diffuse * g_sc : (T)0;
+    V3<T> g_nh = {(T)0, (T)0, (T)0}, g_lh = {(T)0, (T)0, (T)0}, g_p = {(T)0, (T)0, (T)0};
+    if (spec_on) {
+      const T g_spec = (G.x + G.y) + G.z;
+      T dpow;
+      if (cam.ph.shininess == (T)64) {
+        const T a2_ = alpha * alpha, a4 = a2_ * a2_, a8 = a4 * a4, a16 = a8 * a8, a32 = a16 * a16;
+        dpow = (T)64 * (((a32 * a16) * (a8 * a4)) * (a2_ * alpha));
+      } else {
+        dpow = cam.ph.shininess * pow_shininess(alpha, cam.ph.shininess - (T)1);
+      }
+      const T g_dvr = cam.ph.specular * dpow * g_spec;
+      const V3<T> g_vh = {g_dvr * refl.x, g_dvr * refl.y, g_dvr * refl.z};
+      const V3<T> g_r = {g_dvr * vh.x, g_dvr * vh.y, g_dvr * vh.z};
+      g_lh = {-g_r.x, -g_r.y, -g_r.z};
+      g_cos += (T)2 * dot(g_r, nh);
+      g_nh = {(T)2 * cosang * g_r.x, (T)2 * cosang * g_r.y, (T)2 * cosang * g_r.z};
+      const V3<T> g_view = normalize_rs_bwd(vh, idv, cv, g_vh);
+      g_cc = g_view;
+      g_p = {-g_view.x, -g_view.y, -g_view.z};
+    }
+    g_nh = {g_nh.x + g_cos * lh.x, g_nh.y + g_cos * lh.y, g_nh.z + g_cos * lh.z};
+    g_lh = {g_lh.x + g_cos * nh.x, g_lh.y + g_cos * nh.y, g_lh.z + g_cos * nh.z};
+    const V3<T> g_n = normalize_rs_bwd(nh, idn, cn, g_nh);
+    g_l = cam.l_is_unit ? g_lh : normalize_rs_bwd(lh, idl, cl, g_lh);
+    gb0 = (dot(g_p, X0) + dot(g_n, N0)) + dot(g_tex, c0);
+    gb1 = (dot(g_p, X1) + dot(g_n, N1)) + dot(g_tex, c1);
+    gb2 = (dot(g_p, X2) + dot(g_n, N2)) + dot(g_tex, c2);
+  } else {   // texel only (SoftSilhouetteShader's RGB)
+    gb0 = dot(G, c0); gb1 = dot(G, c1); gb2 = dot(G, c2);
+  }
+  // depth: z = sum b_i z_i
+  gb0 += gzbuf * z0; gb1 += gzbuf * z1; gb2 += gzbuf * z2;
+  T gz0 = gzbuf * b0, gz1 = gzbuf * b1, gz2 = gzbuf * b2;
+  // clip backward: b_i = x_i / max(sum x, 1e-5), x_i = clamp(w_i, 0, 1)
+  T gw0 = gb0, gw1 = gb1, gw2 = gb2;
+  if (clip_bary) {
+    const T sdot = s_clamped ? (T)0 : (gb0 * b0 + gb1 * b1) + gb2 * b2;
+    const T gx0 = (gb0 - sdot) * rS, gx1 = (gb1 - sdot) * rS, gx2 = (gb2 - sdot) * rS;
+    gw0 = (w0 > (T)0 && w0 < (T)1) ? gx0 : (T)0;
+    gw1 = (w1 > (T)0 && w1 < (T)1) ? gx1 : (T)0;
+    gw2 = (w2 > (T)0 && w2 < (T)1) ? gx2 : (T)0;
+  }
+  T ga0 = gw0, ga1 = gw1, ga2 = gw2;
+  if (cam.persp) {
+    T gt0, gt1, gt2;
+    if (den_clamped) {
+      gt0 = gw0 * rden; gt1 = gw1 * rden; gt2 = gw2 * rden;
+    } else {
+      const T s_ = (gw0 * w0 + gw1 * w1) + gw2 * w2;
+      gt0 = (gw0 - s_) * rden; gt1 = (gw1 - s_) * rden; gt2 = (gw2 - s_) * rden;
+    }
+    ga0 = gt0 * (z1 * z2); gz1 += gt0 * (a0 * z2); gz2 += gt0 * (a0 * z1);
+    ga1 = gt1 * (z0 * z2); gz0 += gt1 * (a1 * z2); gz2 += gt1 * (z0 * a1);
+    ga2 = gt2 * (z0 * z1); gz0 += gt2 * (z1 * a2); gz1 += gt2 * (z0 * a2);
+  }
+  const T ge0 = ga0 * ra, ge1 = ga1 * ra, ge2 = ga2 * ra;
+  const T g_area = -((ga0 * a0 + ga1 * a1) + ga2 * a2) * ra;
+  T gu0 = (T)0, gv0 = (T)0, gu1 = (T)0, gv1 = (T)0, gu2 = (T)0, gv2 = (T)0;
+  gu1 += ge0 * (py - v2); gv1 += ge0 * (u2 - px); gu2 += ge0 * (v1 - py); gv2 += ge0 * (px - u1);
+  gu2 += ge1 * (py - v0); gv2 += ge1 * (u0 - px); gu0 += ge1 * (v2 - py); gv0 += ge1 * (px - u2);
+  gu0 += ge2 * (py - v1); gv0 += ge2 * (u1 - px); gu1 += ge2 * (v0 - py); gv1 += ge2 * (px - u0);
+  gu2 += g_area * (v1 - v0); gv2 += g_area * (-(u1 - u0));
+  gu0 += g_area * (v2 - v1); gv0 += g_area * (u1 - u2);
+  gu1 += g_area * (v0 - v2); gv1 += g_area * (u2 - u0);
+  // signed squared distance to the nearest edge (a, b): q = a + t (b - a); d|p - q|^2 / da = -2 (1 - t) r, / db = -2 t r
+  if (gdist != (T)0) {
+    int edge;
+    T t;
+    const V3<T> P0 = {u0, v0, z0}, P1 = {u1, v1, z1}, P2 = {u2, v2, z2};
+    (void)point_triangle_dist2(px, py, P0, P1, P2, &edge, &t);
+    const T ax = edge == 2 ? u1 : u0, ay = edge == 2 ? v1 : v0, bx = edge == 0 ? u1 : u2, by = edge == 0 ? v1 : v2;
+    T wa, wb, rx, ry;
+    if (t < (T)0) { wa = (T)0; wb = (T)1; rx = px - bx; ry = py - by; }   // degenerate edge: distance to b
+    else { wa = (T)1 - t; wb = t; rx = px - (ax + t * (bx - ax)); ry = py - (ay + t * (by - ay)); }
+    const T sgn = inside ? (T)-1 : (T)1;
+    const T k = (T)-2 * sgn * gdist;
+    const T gax = k * wa * rx, gay = k * wa * ry, gbx = k * wb * rx, gby = k * wb * ry;
+    if (edge == 2) { gu1 += gax; gv1 += gay; } else { gu0 += gax; gv0 += gay; }
+    if (edge == 0) { gu1 += gbx; gv1 += gby; } else { gu2 += gbx; gv2 += gby; }
+  }
+  auto proj_bwd = [&](T rz, T u, T v, T gu, T gv, T gz, const V3<T> &Xw) {
+    const T gx = gu * cam.s * rz, gy = gv * cam.s * rz;
+    const T gzz = gz - (gu * u + gv * v) * rz;
+    acc[0] += Xw.x * gx; acc[1] += Xw.x * gy; acc[2] += Xw.x * gzz;
+    acc[3] += Xw.y * gx; acc[4] += Xw.y * gy; acc[5] += Xw.y * gzz;
+    acc[6] += Xw.z * gx; acc[7] += Xw.z * gy; acc[8] += Xw.z * gzz;
+    acc[9] += gx; acc[10] += gy; acc[11] += gzz;
+  };
+  proj_bwd(rz0, u0, v0, gu0, gv0, gz0, X0);
+  proj_bwd(rz1, u1, v1, gu1, gv1, gz1, X1);
+  proj_bwd(rz2, u2, v2, gu2, gv2, gz2, X2);
+  acc[12] += g_cc.x; acc[13] += g_cc.y; acc[14] += g_cc.z;
+  acc[15] += g_l.x; acc[16] += g_l.y; acc[17] += g_l.z;
+}
+
+// softmax_rgb_blend / sigmoid_alpha_blend constants (renderer/blending.py): znear 1, zfar 100, eps 1e-10
+MVR_HD float texp(float x) { return expf(x); }
+MVR_HD double texp(double x) { return exp(x); }
+template <typename T> MVR_HD T sigmoid_neg(T d, T sigma) { return (T)1 / ((T)1 + texp(d / sigma)); }   // sigmoid(-d / sigma)
+
 // Fold the per-view camera-centre gradient into (gR, gT):  cc_i = -sum_j T_j R[i][j].
 template <typename T> MVR_HD void fold_camera_center(const T R[9], const T Tr[3], const T gcc[3], T gR[9], T gT[3]) {
   for (int i = 0; i < 3; ++i)

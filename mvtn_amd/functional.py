@@ -312,6 +312,69 @@ def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params, retur
     return (images, p2f) + extra
 
 
+# ---------------------------------------------------------------------------------------------
+# soft mesh path: blur_radius > 0, faces_per_pixel = K, SoftPhongShader / SoftSilhouetteShader
+# ---------------------------------------------------------------------------------------------
+
+def soft_params(blur_radius, faces_per_pixel, shader="soft_phong", sigma=1e-4, gamma=1e-4, clip_barycentric_coords=None):
+    """RasterizationSettings(blur_radius, faces_per_pixel, clip_barycentric_coords) + BlendParams(sigma, gamma) of the
+    reference's imports (models/renderer.py:3-12,:42,:89-93).  clip_barycentric_coords None = PyTorch3D's rule
+    (True when blur_radius > 0)."""
+    if clip_barycentric_coords is None:
+        clip_barycentric_coords = blur_radius > 0
+    sh = {"soft_phong": _lib.MVR_SHADER_SOFT_PHONG, "soft_silhouette": _lib.MVR_SHADER_SOFT_SILHOUETTE}[shader]
+    return _lib.SoftParams(float(blur_radius), float(sigma), float(gamma), int(faces_per_pixel), sh, int(bool(clip_barycentric_coords)))
+
+
+class _RenderMeshesSoft(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R, T, light, packed, params, soft):
+        lib = _lib.load()
+        R, T, light = _f32c(R), _f32c(T), _f32c(light)
+        _require_cuda(R, T, light, packed.verts)
+        B, V, H, W = packed.n_meshes, params.n_views, params.image_h, params.image_w
+        N, K = B * V, soft.faces_per_pixel
+        if R.shape[0] != N or T.shape[0] != N:
+            raise ValueError("R/T must have B*V = %d rows" % N)
+        dev = R.device
+        mb = packed.c_struct()
+        ws_bytes = lib.mvr_mesh_soft_workspace_bytes(mb, params, soft)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        images = torch.empty(B, V, 4, H, W, dtype=torch.float32, device=dev)
+        p2f = torch.empty(N, H, W, K, dtype=torch.int32, device=dev)
+        _lib.check(lib.mvr_render_meshes_soft_forward(mb, params, soft, R.data_ptr(), T.data_ptr(), light.data_ptr(), images.data_ptr(),
+                                                      p2f.data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "mvr_render_meshes_soft_forward")
+        ctx.save_for_backward(R, T, light, p2f, ws)
+        ctx.packed, ctx.params, ctx.soft = packed, params, soft
+        ctx.mark_non_differentiable(p2f)
+        return images, p2f
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        lib = _lib.load()
+        R, T, light, p2f, ws = ctx.saved_tensors
+        packed, params, soft = ctx.packed, ctx.params, ctx.soft
+        g = _f32c(g)
+        N = R.shape[0]
+        bparams = _lib.MeshParams.from_buffer_copy(params)
+        bparams.flags |= _lib.MVR_WORKSPACE_FROM_FORWARD
+        gR, gT = torch.empty_like(R), torch.empty_like(T)
+        per_view_light = params.n_light == N and N > 0 and ctx.needs_input_grad[2]
+        gL = torch.empty(N, 3, dtype=torch.float32, device=R.device) if per_view_light else None
+        _lib.check(lib.mvr_render_meshes_soft_backward(packed.c_struct(), bparams, soft, R.data_ptr(), T.data_ptr(), light.data_ptr(),
+                                                       p2f.data_ptr(), g.data_ptr(), gR.data_ptr(), gT.data_ptr(), _ptr(gL),
+                                                       ws.data_ptr(), ws.numel(), _stream()), "mvr_render_meshes_soft_backward")
+        return gR, gT, gL, None, None, None
+
+
+def render_meshes_soft(packed: PackedMeshes, R, T, light_dir, params, soft, return_fragments=False):
+    """RGBA images (B,V,4,H,W) of MeshRenderer(MeshRasterizer(blur_radius, faces_per_pixel), SoftPhongShader /
+    SoftSilhouetteShader); differentiable w.r.t. R, T and a per-view light_dir — including the coverage gradient
+    through the signed distances (alpha and the softmax weights).  `return_fragments`: also pix_to_face (N,H,W,K)."""
+    images, p2f = _RenderMeshesSoft.apply(R, T, light_dir, packed, params, soft)
+    return (images, p2f) if return_fragments else images
+
+
 def render_points_fragments(points, colors, R, T, dist, params):
     """(images, pix_to_point int32: (N,H,W) for points_per_pixel == 1, else (N,H,W,K)) without autograd — for parity tests."""
     lib = _lib.load()

@@ -34,7 +34,8 @@ _STATUS_PENDING = -1   # sentinel in the pinned status words until the look-at k
 class MVRenderer(nn.Module):
     def __init__(self, nb_views, image_size=224, pc_rendering=True, object_color="white", background_color="white",
                  faces_per_pixel=1, points_radius=0.006, points_per_pixel=1, light_direction="random",
-                 cull_backfaces=False, *, perspective_correct=True, rotation_check="device", strip_rows=0, z_clip=None):
+                 cull_backfaces=False, *, perspective_correct=True, rotation_check="device", strip_rows=0, z_clip=None,
+                 shader="hard_phong", blur_radius=0.0, sigma=1e-4, gamma=1e-4, return_alpha=False):
         super().__init__()
         self.nb_views = nb_views
         self.image_size = image_size
@@ -58,6 +59,9 @@ class MVRenderer(nn.Module):
         self._color_cache = {}  # colour name -> 3 floats
         self._params_cache = {}
         self.strip_rows = strip_rows
+        if shader not in ("hard_phong", "soft_phong", "soft_silhouette"):
+            raise ValueError("shader must be 'hard_phong', 'soft_phong' or 'soft_silhouette'")
+        self.shader, self.blur_radius, self.sigma, self.gamma, self.return_alpha = shader, blur_radius, sigma, gamma, return_alpha
         # faces_per_pixel > 1 does not change a HardPhongShader image (hard_rgb_blend reads only
         # the nearest face), so any value >= 1 renders identically; points_per_pixel = K > 1 does change
         # the image (norm-weighted sum over the K nearest points) and runs the top-K rasteriser.
@@ -191,6 +195,8 @@ class MVRenderer(nn.Module):
                                                               strip_rows=self.strip_rows, z_clip=self.z_clip)
         if azim.numel() != N:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (packed.n_meshes, self.nb_views))
+        if self.shader != "hard_phong":
+            return self._render_meshes_soft(packed, azim, elev, dist, light, params)
         # look-at (+ remedy) -> light -> rasterise + shade as ONE autograd node
         max_trials, seed, host = -1, 0, None
         if self.rotation_check == "device":
@@ -207,6 +213,20 @@ class MVRenderer(nn.Module):
                 light = F.camera_position_from_spherical_angles(flatten_views(dist), flatten_views(elev), flatten_views(azim))
             images = F.render_meshes(packed, R, T, light, params)
         return images, Cameras(R, T, "perspective")
+
+    def _render_meshes_soft(self, packed, azim, elev, dist, light, params):
+        """The shaders the reference imports but never switches on (models/renderer.py:3-12; knobs at :42,:89-93):
+        blur_radius / faces_per_pixel rasterisation + SoftPhongShader or SoftSilhouetteShader, as chained autograd
+        nodes (look-at -> [camera-position light] -> soft render).  Returns RGB (B,V,3,H,W) like the reference's
+        `[..., 0:3]` slice, or RGBA (B,V,4,H,W) with `return_alpha` (the silhouette lives in the alpha channel)."""
+        R, T, status = self._cameras(azim, elev, dist)
+        if self.rotation_check == "sync" and int(status[1].item()) != 0:
+            R, T = self._remedy(azim, elev, dist)
+        if light is None:
+            light = F.camera_position_from_spherical_angles(flatten_views(dist), flatten_views(elev), flatten_views(azim))
+        soft = F.soft_params(self.blur_radius, self.faces_per_pixel, self.shader, self.sigma, self.gamma)
+        rgba = F.render_meshes_soft(packed, R, T, light, params, soft)
+        return (rgba if self.return_alpha else rgba[:, :, 0:3]), Cameras(R, T, "perspective")
 
     # -- models/renderer.py:116-151 ----------------------------------------------------------------
     def render_points(self, points, color, azim, elev, dist, background_color=(0.0, 0.0, 0.0)):

@@ -153,6 +153,42 @@ def render_meshes(verts_list, faces_list, azim, elev, dist, image_size, light_di
     return dict(images=images, pix_to_face=p2f, zbuf=zbuf, bary=bary, R=R, T=T, straddlers=straddlers)
 
 
+def render_meshes_soft(verts_list, faces_list, azim, elev, dist, image_size, blur_radius, faces_per_pixel, shader="soft_phong",
+                       sigma=1e-4, gamma=1e-4, clip_barycentric_coords=True, light_dir=((0.0, 1.0, 0.0),),
+                       obj_color=(1.0, 1.0, 1.0), bg_color=(1.0, 1.0, 1.0), vert_colors=None, perspective_correct=True,
+                       cull_backfaces=False, fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0,
+                       fixed_p2f=None, dtype=np.float32, R=None, T=None, z_clip=0.0):
+    """Soft rasterisation + SoftPhongShader ("soft_phong") / SoftSilhouetteShader ("soft_silhouette") — SURVEY 8 f4.
+    Returns dict(images (B,V,4,H,W) RGBA, pix_to_face / zbuf / dists (N,H,W,K), bary (N,H,W,K,3), R, T)."""
+    sfx, cty = _sfx(dtype)
+    azim = np.asarray(azim, dtype)
+    B, V = azim.shape
+    N, K = B * V, int(faces_per_pixel)
+    assert 1 <= K <= 64
+    H = W = int(image_size)
+    verts, faces, vert_off, face_off = pack_meshes(verts_list, faces_list, dtype)
+    if R is None:
+        R, T = look_at(azim, elev, dist, dtype)
+    R, T = np.ascontiguousarray(R, dtype), np.ascontiguousarray(T, dtype)
+    light = np.ascontiguousarray(np.asarray(light_dir, dtype).reshape(-1, 3))
+    assert light.shape[0] in (1, N)
+    vc = None if vert_colors is None else np.ascontiguousarray(np.asarray(vert_colors, dtype).reshape(-1, 3))
+    oc, bg = _flat(obj_color, dtype), _flat(bg_color, dtype)
+    images = np.empty((B, V, 4, H, W), dtype)
+    p2f = np.empty((N, H, W, K), np.int32)
+    zbuf, dists, bary = np.empty((N, H, W, K), dtype), np.empty((N, H, W, K), dtype), np.empty((N, H, W, K, 3), dtype)
+    fixed = None if fixed_p2f is None else np.ascontiguousarray(fixed_p2f, np.int32)
+    getattr(lib(), "orc_render_meshes_soft" + sfx)(
+        ctypes.c_int(B), ctypes.c_int(V), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(K),
+        _ptr(verts), _ptr(faces), _ptr(vert_off), _ptr(face_off), _ptr(R), _ptr(T),
+        _ptr(light), ctypes.c_int(light.shape[0]), _ptr(vc), _ptr(oc), _ptr(bg),
+        ctypes.c_int(int(perspective_correct)), ctypes.c_int(int(clip_barycentric_coords)), ctypes.c_int(int(cull_backfaces)),
+        cty(fov), cty(ambient), cty(diffuse), cty(specular), cty(shininess), cty(blur_radius), cty(sigma), cty(gamma),
+        ctypes.c_int({"soft_phong": 0, "soft_silhouette": 1}[shader]), _ptr(fixed), cty(z_clip),
+        _ptr(images), _ptr(p2f), _ptr(zbuf), _ptr(dists), _ptr(bary))
+    return dict(images=images, pix_to_face=p2f, zbuf=zbuf, dists=dists, bary=bary, R=R, T=T)
+
+
 def render_points(points, azim, elev, dist, image_size, radius=0.006, obj_color=(1.0, 1.0, 1.0),
                   bg_color=(1.0, 1.0, 1.0), point_colors=None, mode=1, fixed_idx=None,
                   dtype=np.float32, R=None, T=None, return_fragments=True, points_per_pixel=1):

@@ -362,3 +362,70 @@ def test_oracle_against_the_torch_restatement_of_c1(oracle):
     assert diff[~differ].max() <= 1e-5
     zz = np.abs(out["zbuf"] - fx["zbuf"])[~differ & (q >= 0)]
     assert zz.max() <= 5e-5
+
+
+# ---- soft path ---------------------------------------------------------------------------------------
+
+def test_ka13_soft_path_with_one_face_per_pixel_and_no_blur_is_the_hard_render(oracle):
+    """KA13: blur_radius = 0, faces_per_pixel = 1: the soft rasteriser keeps exactly the hard rasteriser's fragments, and
+    softmax_rgb_blend of a single fragment returns its colour (w c + 1e-10 bg) / (w + 1e-10): coverage identical, RGB
+    within 1e-6 of the hard Phong image, alpha = sigmoid(d^2 / sigma) of the distance to the nearest edge."""
+    v, f = syn.synthetic_mesh("S", 2)
+    az, el, di = syn.circular_views(3)
+    kw = dict(obj_color=(0.9, 0.8, 0.7), bg_color=(0.1, 0.2, 0.3), dtype=np.float64)
+    hard = oracle.render_meshes([v], [f], az[None], el[None], di[None], 48, **kw)
+    soft = oracle.render_meshes_soft([v], [f], az[None], el[None], di[None], 48, 0.0, 1, **kw)
+    assert np.array_equal(soft["pix_to_face"][..., 0], hard["pix_to_face"])
+    cov = hard["pix_to_face"] >= 0
+    d = np.abs(soft["images"][0, :, :3] - hard["images"][0]).max(1)
+    assert d[cov].max() < 1e-6 and d[~cov].max() < 1e-12
+    a = soft["images"][0, :, 3]
+    assert np.abs(a[cov] - 1 / (1 + np.exp(soft["dists"][..., 0][cov] / 1e-4))).max() < 1e-12 and (a[~cov] == 0).all()
+    assert (soft["dists"][..., 0][cov] < 0).all()
+
+
+def test_ka14_soft_silhouette_of_a_triangle_is_the_sigmoid_of_the_signed_distance(oracle):
+    """KA14: one fronto-parallel triangle, identity camera: alpha(p) = sigmoid(-sd(p) / sigma) with sd = the signed squared
+    Euclidean distance of the pixel centre to the triangle in NDC (negative inside), for every pixel nearer than
+    sqrt(blur_radius); 0 beyond.  Distance computed here independently (numpy, point-to-segment)."""
+    V = np.array([[-0.4, -0.3, 2.0], [0.5, -0.2, 2.0], [0.0, 0.45, 2.0]])
+    f = np.array([[0, 1, 2]], np.int64)
+    S, sigma = 40, 1e-3
+    blur = float(np.log(1 / 1e-4 - 1) * sigma)
+    one = np.zeros((1, 1))
+    out = oracle.render_meshes_soft([V], [f], one, one, one + 1, S, blur, 2, shader="soft_silhouette", sigma=sigma,
+                                    R=np.eye(3)[None], T=np.zeros((1, 3)), dtype=np.float64)
+    s = 1 / np.tan(np.radians(30))
+    P = np.stack([s * V[:, 0] / V[:, 2], s * V[:, 1] / V[:, 2]], 1)
+
+    def seg(p, a, b):
+        t = np.clip(np.dot(b - a, p - a) / np.dot(b - a, b - a), 0, 1)
+        return float(((p - (a + t * (b - a))) ** 2).sum())
+    n_band = 0
+    for yi in range(S):
+        for xi in range(S):
+            p = np.array([1 - (2 * xi + 1) / S, 1 - (2 * yi + 1) / S])
+            d2 = min(seg(p, P[0], P[1]), seg(p, P[0], P[2]), seg(p, P[1], P[2]))
+            e = [(p[0] - P[i][0]) * (P[j][1] - P[i][1]) - (p[1] - P[i][1]) * (P[j][0] - P[i][0]) for i, j in ((0, 1), (1, 2), (2, 0))]
+            inside = all(x > 0 for x in e) or all(x < 0 for x in e)
+            want = 1 / (1 + np.exp((-d2 if inside else d2) / sigma)) if (inside or d2 < blur) else 0.0
+            if abs(d2 - blur) < 1e-9:
+                continue
+            assert abs(out["images"][0, 0, 3, yi, xi] - want) < 1e-9, (xi, yi)
+            n_band += (not inside) and d2 < blur
+    assert n_band > 30   # the blur band is several pixels wide at this sigma
+
+
+def test_soft_oracle_fragment_lists_are_sorted_and_fixed_lists_reproduce_the_render(oracle):
+    v, f = syn.synthetic_mesh("S", 5)
+    az, el, di = syn.circular_views(2)
+    sigma = 1e-4
+    blur = float(np.log(1 / 1e-4 - 1) * sigma)
+    out = oracle.render_meshes_soft([v], [f], az[None], el[None], di[None], 40, blur, 6, dtype=np.float64)
+    pf, zb = out["pix_to_face"], out["zbuf"]
+    valid = pf >= 0
+    assert (valid[..., 1:] <= valid[..., :-1]).all()                      # compact lists
+    both = valid[..., 1:] & valid[..., :-1]
+    assert (zb[..., 1:][both] >= zb[..., :-1][both]).all()                # ascending depth
+    again = oracle.render_meshes_soft([v], [f], az[None], el[None], di[None], 40, blur, 6, dtype=np.float64, fixed_p2f=pf)
+    assert np.abs(again["images"] - out["images"]).max() < 1e-12 and np.abs(again["dists"] - out["dists"]).max() < 1e-15
