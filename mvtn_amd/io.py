@@ -114,3 +114,46 @@ def mesh_from_file(path, angle=-90.0, rot_axis=(1, 0, 0), dset_norm=2, flip_face
     verts = rotation_matrix(rot_axis, angle).dot(verts.T).T
     verts = torch_center_and_normalize(torch.from_numpy(verts).to(torch.float), p=dset_norm)
     return Meshes([verts], [torch.from_numpy(faces)])
+
+
+# ---- ScanObjectNN point clouds (custom_dataset.py:485-575) ------------------------------------------------------------
+
+def load_scanobjectnn_bin(path, variant="obj_only", suncg=False):
+    """custom_dataset.py:553-575 `ScanObjectNN.load_pc_file`: a .bin record is float32 values — the point count, then one
+    row per point: x y z nx ny nz r g b instance semantic (11 columns; 3 for the SUNCG export).  "with_bg": every point's
+    xyz.  Otherwise: the points of the LARGEST foreground instance (last column, instances 0 / 1 / 2 are background;
+    ties go to the smallest instance id, as np.unique + argmax do)."""
+    pc = np.fromfile(path, dtype=np.float32)
+    pc = pc[1:].reshape((-1, 3 if suncg else 11))
+    if variant == "with_bg":
+        return np.array(pc[:, 0:3])
+    lab = pc[:, -1]
+    fg = lab[(lab != 0) & (lab != 1) & (lab != 2)]
+    values, counts = np.unique(fg, return_counts=True)
+    return np.array(pc[lab == values[np.argmax(counts)], 0:3])
+
+
+def load_scanobjectnn_h5(path):
+    """custom_dataset.py:515-520 (the "hardest" variant): (data (n, P, 3) float32, label (n,)) of an
+    *_objectdataset_augmentedrot_scale75.h5 file.  Needs h5py (not part of this image: the error says so)."""
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError("load_scanobjectnn_h5 needs h5py, which is not installed here; the .bin variants need numpy only") from e
+    with h5py.File(path, "r") as f:
+        return np.array(f["data"]), np.array(f["label"])
+
+
+def scanobjectnn_points(points, nb_points=2048, dset_norm=2, rng=None):
+    """custom_dataset.py:524-545 `__getitem__`: draw nb_points indices WITH replacement (np.random.randint), convert to a
+    float tensor, centre + normalise (util.py:437-451).  `rng`: None = numpy's global generator like the reference, or a
+    numpy Generator / RandomState for a reproducible draw."""
+    points = np.asarray(points)
+    n = points.shape[0]
+    if rng is None:
+        idx = np.random.randint(n, size=nb_points)
+    elif hasattr(rng, "integers"):
+        idx = rng.integers(0, n, size=nb_points)
+    else:
+        idx = rng.randint(n, size=nb_points)
+    return torch_center_and_normalize(torch.from_numpy(points[idx, :]).to(torch.float), p=dset_norm)

@@ -1,9 +1,13 @@
 """Mesh ingestion: OFF / OBJ parsing and the dataset-side normalisation, CPU only."""
+import importlib.util
+
 import numpy as np
 import pytest
 import torch
 
 from mvtn_amd import io as mio
+
+io = mio
 
 CUBE_OFF = """OFF
 # a cube with quad faces
@@ -75,3 +79,28 @@ def test_mesh_from_file_yields_what_the_renderer_takes(tmp_path):
     assert abs(float(v.norm(dim=1).max()) - 1.0) < 1e-6 and torch.allclose(v.mean(0), torch.zeros(3), atol=1e-6)
     m2 = mio.mesh_from_file(str(p), flip_faces=True)
     assert _signed_volume(m2.verts_list()[0].numpy().astype(np.float64), m2.faces_list()[0].numpy()) < 0
+
+
+def test_scanobjectnn_bin_matches_the_reference_loader(tmp_path):
+    """custom_dataset.py:553-575 ran on synthetic .bin records when tests/golden/scanobjectnn_bin.npz was made
+    (tests/golden/make_scanobjectnn_golden.py): same points, bit for bit, for the object-only, with-background and SUNCG
+    variants and for a tie between two foreground instances."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "scanobjectnn_bin.npz"))
+    assert len(fx["names"]) == 4
+    for name in fx["names"]:
+        name = str(name)
+        suncg, with_bg = (int(x) for x in fx["cfg_" + name])
+        p = tmp_path / (name + ".bin")
+        fx["raw_" + name].tofile(str(p))
+        got = io.load_scanobjectnn_bin(str(p), "with_bg" if with_bg else "obj_only", bool(suncg))
+        assert got.dtype == np.float32 and np.array_equal(got, fx["pts_" + name]), name
+    pts = io.scanobjectnn_points(fx["pts_obj"], 256, 2, np.random.RandomState(0))
+    np.random.seed(0)
+    ref = fx["pts_obj"][np.random.randint(fx["pts_obj"].shape[0], size=256), :]      # the reference's draw
+    want = io.torch_center_and_normalize(torch.from_numpy(ref).to(torch.float), p=2)
+    assert pts.shape == (256, 3) and torch.equal(pts, want)
+    assert abs(float(pts.norm(dim=1).max()) - 1.0) < 1e-6
+    if importlib.util.find_spec("h5py") is None:
+        with pytest.raises(ImportError, match="h5py"):
+            io.load_scanobjectnn_h5(str(tmp_path / "x.h5"))
