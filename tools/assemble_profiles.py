@@ -23,7 +23,7 @@ def pmc(dirn, kern):
     return vals
 
 
-for w in ("mesh_fwd", "mesh_fwdbwd", "points_fwd"):
+for w in ("mesh_fwd", "mesh_fwdbwd", "points_fwd", "c5"):
     f = glob.glob("%s/stats_%s/**/*kernel_stats.csv" % (src, w), recursive=True)[0]
     shutil.copy(f, "%s/%s_kernel_stats_%s.csv" % (dst, tag, w))
     shutil.copy("%s/bench_%s.json" % (src, w), "%s/%s_bench_%s.json" % (dst, tag, w))
@@ -33,8 +33,8 @@ for w in ("mesh_fwd", "mesh_fwdbwd", "points_fwd"):
 note = ("separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `rocprofv3 --pmc X --output-format csv -- python3 bench.py --steps 5 --warmup 2 "
         "--no-cpu-baseline [--workload W]` (tools/collect_profiles.sh), averaged per launch; gfx950 correction: FETCH_SIZE doubled "
         "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE calibrated on the points kernel (235200 KiB == its 240 844 800 output bytes)")
-for w, kern, out in (("mesh_fwd", "k_mesh_raster_shade", "traffic_mesh_fwd.json"), ("points_fwd", "k_points_raster_shade", "traffic_points_fwd.json"),
-                     ("mesh_fwdbwd", "k_mesh_backward(", "traffic_mesh_bwd_kernel.json")):
+for w, kern, out in (("mesh_fwd", "k_mesh_raster_fast", tag + "_traffic_mesh_fwd.json"), ("points_fwd", "k_points_raster_shade", tag + "_traffic_points_fwd.json"),
+                     ("mesh_fwdbwd", "k_mesh_raster_fast", tag + "_traffic_mesh_fwdbwd.json"), ("mesh_fwdbwd", "k_mesh_backward(", tag + "_traffic_mesh_bwd_kernel.json")):
     fe = pmc("%s/pmc_FETCH_SIZE_%s" % (src, w), kern)["FETCH_SIZE"]
     wr = pmc("%s/pmc_WRITE_SIZE_%s" % (src, w), kern)["WRITE_SIZE"]
     d = {"kernel": kern.rstrip("("), "FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": int((2 * fe + wr) * 1024), "note": note}
@@ -43,10 +43,11 @@ for w, kern, out in (("mesh_fwd", "k_mesh_raster_shade", "traffic_mesh_fwd.json"
 fe = pmc("%s/pmc_FETCH_SIZE_mesh_fwd" % src, "k_mesh_prepass")["FETCH_SIZE"]
 wr = pmc("%s/pmc_WRITE_SIZE_mesh_fwd" % src, "k_mesh_prepass")["WRITE_SIZE"]
 sq = {}
-for kern in ("k_mesh_raster_shade", "k_mesh_backward(", "k_mesh_prepass"):
+for kern in ("k_mesh_raster_fast", "k_mesh_backward(", "k_mesh_prepass"):
     v = {}
     v.update(pmc("%s/pmc_sq1_mesh_fwdbwd" % src, kern))
     v.update(pmc("%s/pmc_sq2_mesh_fwdbwd" % src, kern))
+    v.update(pmc("%s/pmc_sq3_mesh_fwdbwd" % src, kern))
     sq[kern.rstrip("(")] = v
 sq["k_points_raster_shade"] = pmc("%s/pmc_sq1_points_fwd" % src, "k_points_raster_shade")
 sq["_note"] = ("rocprofv3 --pmc passes of tools/collect_profiles.sh (C3 step for the mesh kernels, C4 for the points kernel); SQ_*_CYCLES / "

@@ -1,19 +1,23 @@
 # Collects the round's judged measurements on the GPU box into gpurun_out/$1 (run from the repo root through gpurun):
-#   bench lines (un-profiled), rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE passes and one SQ counter pass.
+#   bench lines (un-profiled), rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE passes and SQ counter passes.
+# Every profiler run is bounded by `timeout` (a counter combination that stalls must not eat the GPU budget).
 out=gpurun_out/${1:-prof}
 mkdir -p $out
 export TMPDIR=/tmp
+for w in mesh_fwd mesh_fwdbwd points_fwd c5; do
+  timeout 300 python3 bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$w -- python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+done
 for w in mesh_fwd mesh_fwdbwd points_fwd; do
-  python3 bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$w -- python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $out/pmc_${c}_$w -- python3 bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+    timeout 200 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${c}_$w -- python3 bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
   done
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_sq1_mesh_fwdbwd -- python3 bench.py --workload mesh_fwdbwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $out/pmc_sq2_mesh_fwdbwd -- python3 bench.py --workload mesh_fwdbwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_sq1_points_fwd -- python3 bench.py --workload points_fwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_sq1_mesh_fwdbwd -- python3 bench.py --workload mesh_fwdbwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $out/pmc_sq2_mesh_fwdbwd -- python3 bench.py --workload mesh_fwdbwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL --output-format csv -d $out/pmc_sq3_mesh_fwdbwd -- python3 bench.py --workload mesh_fwdbwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_sq1_points_fwd -- python3 bench.py --workload points_fwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 find $out -name "*kernel_trace.csv" -delete
 find $out -name "*agent_info.csv" -delete
 du -sh $out
-for w in mesh_fwd mesh_fwdbwd points_fwd; do tail -1 $out/bench_$w.json | cut -c1-400; done
+for w in mesh_fwd mesh_fwdbwd points_fwd c5; do tail -1 $out/bench_$w.json | cut -c1-400; done
