@@ -115,13 +115,45 @@ template <typename T> MVR_HD V3<T> normalize_bwd(const V3<T> &out, T d, bool cla
 
 // ---- cameras --------------------------------------------------------------------------
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// sin and cos of a double on the device, for |x| < 1.5e6 (any angle a view selector can produce, in radians): Cody-Waite
+// reduction by pi/2 in three parts + the fdlibm kernel polynomials (errors < 1 ulp of a DOUBLE).  The device library's
+// generic sincos(double) spends several hundred instructions per call (it carries the Payne-Hanek path for huge
+// arguments); it was the largest single consumer of VALU time in the pre-pass kernels, where every view workgroup
+// evaluates the look-at of all views.  The result is only ever rounded to float: like the library's it equals the
+// correctly rounded float unless the true value lies within ~1e-16 (relative) of a float rounding boundary.
+__device__ __forceinline__ void sincos_f64_small(double x, double *sn, double *cs) {
+  const double k = __builtin_rint(x * 6.36619772367581382433e-01);   // 2 / pi
+  double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);      // pi/2, first 33 bits
+  r = __builtin_fma(-k, 6.07710050630396597660e-11, r);             // next 33 bits
+  r = __builtin_fma(-k, 2.02226624871116645580e-21, r);             // next 33 bits
+  const double tail = __builtin_fma(-k, 8.47842766036889956997e-32, 0.0);   // what is left of pi/2 beyond 99 bits
+  const double z = r * r;
+  // __kernel_sin / __kernel_cos of fdlibm on [-pi/4, pi/4]
+  const double ps = z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                    z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double s_ = r + (r * z) * (-1.66666666666666324348e-01 + ps) + tail;
+  const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double c_ = w + (((1.0 - w) - hz) + (z * pc - r * tail));
+  const int q = (int)k & 3;
+  const double ss = (q & 1) ? c_ : s_, cc = (q & 1) ? s_ : c_;
+  *sn = (q & 2) ? -ss : ss;
+  *cs = ((q + 1) & 2) ? -cc : cc;
+}
+#endif
+
 // sin/cos of an angle in degrees: rad = float(pi/180) * deg in T, then correctly rounded
 // sin/cos (evaluate in double, round once).
 template <typename T> MVR_HD void sincos_deg(T deg, T *s, T *c) {
   T rad = (T)(kPi / 180.0) * deg;
 #if defined(__HIP_DEVICE_COMPILE__)
-  double sd, cd;            // one argument reduction for both (the device library's sincos returns the values of its sin / cos)
-  sincos((double)rad, &sd, &cd);
+  double sd, cd;
+  const double xd = (double)rad;
+  if (__builtin_fabs(xd) < 1.5e6) sincos_f64_small(xd, &sd, &cd);
+  else sincos(xd, &sd, &cd);    // (huge or non-finite angles: the library's full-range path)
   *s = (T)sd; *c = (T)cd;
 #else
   *s = (T)sin((double)rad);
