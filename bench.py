@@ -262,7 +262,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC passes of the same command, committed under profiles/ (FETCH_SIZE / WRITE_SIZE
     # cannot be read inside this process); `from_profiles` names the file so that a stale number is visible as such
     traffic, traffic_src = None, None
-    for tpath in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % args.workload)))[-1:]:
+    for tpath in ([] if c5 else sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % args.workload)))[-1:]):
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             traffic_src = os.path.relpath(tpath, ROOT)

@@ -6,7 +6,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 for w in mesh_fwd mesh_fwdbwd points_fwd c5; do
   timeout 300 python3 bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$w -- python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$w -- python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-pipelined > /dev/null 2>&1
 done
 for w in mesh_fwd mesh_fwdbwd points_fwd; do
   for c in FETCH_SIZE WRITE_SIZE; do
