@@ -47,8 +47,10 @@ enum {
   MVR_PERSPECTIVE_CORRECT = 2, /* PyTorch3D >=0.5 default for perspective cameras */
   MVR_WORKSPACE_FROM_FORWARD = 4, /* mvr_render_meshes_backward only: `workspace` is the (unmodified) buffer the
                                     matching mvr_render_meshes_forward call used -> its vertex normals are reused */
-  MVR_RASTER_EXACT_ONLY = 8    /* forward only: skip the fast rasteriser (exact coverage + provably ordered affine inverse
+  MVR_RASTER_EXACT_ONLY = 8,   /* forward only: skip the fast rasteriser (exact coverage + provably ordered affine inverse
                                   depth) and run every strip through the exact-arithmetic kernel; same images, slower */
+  MVR_BACKWARD_GATHER = 16     /* backward only: skip the face-table kernel (per-face data fetched once per strip into LDS)
+                                  and gather per covered pixel; same gradients up to summation order, slower */
 };
 
 /* A batch of B triangle meshes packed back to back (what models/renderer.py:66-77 builds

@@ -14,6 +14,7 @@ MVR_CULL_BACKFACES = 1
 MVR_PERSPECTIVE_CORRECT = 2
 MVR_WORKSPACE_FROM_FORWARD = 4
 MVR_RASTER_EXACT_ONLY = 8
+MVR_BACKWARD_GATHER = 16
 MVR_SHADER_SOFT_PHONG, MVR_SHADER_SOFT_SILHOUETTE = 0, 1
 
 

@@ -113,6 +113,7 @@ struct ProfScope {
 #include "mvr_mesh_raster.inc"
 #include "mvr_mesh_raster_fast.inc"
 #include "mvr_mesh_backward.inc"
+#include "mvr_mesh_backward_tab.inc"
 #include "mvr_mesh_soft.inc"
 #include "mvr_points.inc"
 #include "mvr_abi.inc"

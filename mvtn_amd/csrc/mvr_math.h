@@ -438,24 +438,42 @@ template <typename T> struct PixelGradIn {
                             // the caller applies normalize_rs_bwd once per view (it is linear in that gradient)
 };
 
-template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T px, T py,
-                                                  const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
-                                                  const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
-                                                  const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
-                                                  const V3<T> &G, T acc[18]) {
+// What the per-pixel backward needs of a face that does not depend on the pixel: the projected vertices, the
+// reciprocals of their depths and of the (eps-shifted) area.  k_mesh_backward_tab computes it once per face and strip.
+template <typename T> struct FaceProjected { T u0, v0, z0, rz0, u1, v1, z1, rz1, u2, v2, z2, rz2, ra; };
+template <typename T> MVR_HD FaceProjected<T> face_project_for_bwd(const PixelGradIn<T> &cam, const V3<T> &X0, const V3<T> &X1, const V3<T> &X2) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+  FaceProjected<T> f;
+  const V3<T> Xv0 = world_to_view(cam.R, cam.Tr, X0), Xv1 = world_to_view(cam.R, cam.Tr, X1), Xv2 = world_to_view(cam.R, cam.Tr, X2);
+  f.rz0 = trcp(Xv0.z); f.rz1 = trcp(Xv1.z); f.rz2 = trcp(Xv2.z);
+  f.u0 = (cam.s * Xv0.x) * f.rz0; f.v0 = (cam.s * Xv0.y) * f.rz0; f.z0 = Xv0.z;
+  f.u1 = (cam.s * Xv1.x) * f.rz1; f.v1 = (cam.s * Xv1.y) * f.rz1; f.z1 = Xv1.z;
+  f.u2 = (cam.s * Xv2.x) * f.rz2; f.v2 = (cam.s * Xv2.y) * f.rz2; f.z2 = Xv2.z;
+  const T area = edge_fn(f.u2, f.v2, f.u0, f.v0, f.u1, f.v1) + (T)kEps;
+  f.ra = trcp(area);
+  return f;
+}
+
+// `mid` runs between the shading part and the geometric part.  The face's data (fp, X, N) are not used across it: a caller
+// that holds them in fast memory may let `mid` re-read them there (they are passed by reference and read again after it)
+// instead of keeping ~40 registers alive through the shading arithmetic (k_mesh_backward_tab).
+struct NoMid { MVR_HD void operator()() const {} };
+template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_pre(const PixelGradIn<T> &cam, T px, T py, const FaceProjected<T> &fp,
+                                                      const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
+                                                      const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
+                                                      const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
+                                                      const V3<T> &G, T acc[18], Mid mid = Mid()) {
   // Gradient arithmetic: no coverage decision depends on it, so quotients go through shared reciprocals
   // (trcp / trsq) and the compiler may contract multiply-adds.
 #if defined(__clang__)
 #pragma clang fp contract(fast)
 #endif
   // ---- forward recompute -------------------------------------------------
-  V3<T> Xv0 = world_to_view(cam.R, cam.Tr, X0), Xv1 = world_to_view(cam.R, cam.Tr, X1), Xv2 = world_to_view(cam.R, cam.Tr, X2);
-  const T rz0 = trcp(Xv0.z), rz1 = trcp(Xv1.z), rz2 = trcp(Xv2.z);
-  T u0 = (cam.s * Xv0.x) * rz0, v0 = (cam.s * Xv0.y) * rz0, z0 = Xv0.z;
-  T u1 = (cam.s * Xv1.x) * rz1, v1 = (cam.s * Xv1.y) * rz1, z1 = Xv1.z;
-  T u2 = (cam.s * Xv2.x) * rz2, v2 = (cam.s * Xv2.y) * rz2, z2 = Xv2.z;
-  T area = edge_fn(u2, v2, u0, v0, u1, v1) + (T)kEps;
-  const T ra = trcp(area);
+  T rz0 = fp.rz0, rz1 = fp.rz1, rz2 = fp.rz2;
+  T u0 = fp.u0, v0 = fp.v0, z0 = fp.z0, u1 = fp.u1, v1 = fp.v1, z1 = fp.z1, u2 = fp.u2, v2 = fp.v2, z2 = fp.z2;
+  T ra = fp.ra;
   T e0 = edge_fn(px, py, u1, v1, u2, v2), e1 = edge_fn(px, py, u2, v2, u0, v0), e2 = edge_fn(px, py, u0, v0, u1, v1);
   T a0 = e0 * ra, a1 = e1 * ra, a2 = e2 * ra;
   T w0 = a0, w1 = a1, w2 = a2, rden = (T)1;
@@ -515,6 +533,10 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
   g_lh = {g_lh.x + g_cos * nh.x, g_lh.y + g_cos * nh.y, g_lh.z + g_cos * nh.z};
   V3<T> g_n = normalize_rs_bwd(nh, idn, cn, g_nh);
   V3<T> g_l = cam.l_is_unit ? g_lh : normalize_rs_bwd(lh, idl, cl, g_lh);
+  mid();
+  rz0 = fp.rz0; rz1 = fp.rz1; rz2 = fp.rz2;
+  u0 = fp.u0; v0 = fp.v0; z0 = fp.z0; u1 = fp.u1; v1 = fp.v1; z1 = fp.z1; u2 = fp.u2; v2 = fp.v2; z2 = fp.z2;
+  ra = fp.ra;
   // barycentric gradients
   T gw0 = (dot(g_p, X0) + dot(g_n, N0)) + dot(g_tex, c0);
   T gw1 = (dot(g_p, X1) + dot(g_n, N1)) + dot(g_tex, c1);
@@ -560,6 +582,14 @@ template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T p
   proj_bwd(rz2, u2, v2, gu2, gv2, gz2, X2);
   acc[12] += g_cc.x; acc[13] += g_cc.y; acc[14] += g_cc.z;
   acc[15] += g_l.x; acc[16] += g_l.y; acc[17] += g_l.z;
+}
+
+template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T px, T py,
+                                                  const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
+                                                  const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
+                                                  const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
+                                                  const V3<T> &G, T acc[18]) {
+  phong_pixel_bwd_pre(cam, px, py, face_project_for_bwd(cam, X0, X1, X2), X0, X1, X2, N0, N1, N2, c0, c1, c2, G, acc);
 }
 
 

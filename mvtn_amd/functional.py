@@ -125,8 +125,10 @@ def camera_position_from_spherical_angles(distance, elevation, azimuth):
 # ---------------------------------------------------------------------------------------------
 
 def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backfaces=False, perspective_correct=True,
-                fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, strip_rows=0, exact_raster=False, z_clip=None):
+                fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, strip_rows=0, exact_raster=False, z_clip=None,
+                gather_backward=False):
     """`exact_raster`: skip the fast rasteriser (MVR_RASTER_EXACT_ONLY); the images are the same either way.
+    `gather_backward`: skip the face-table backward kernel (MVR_BACKWARD_GATHER); same gradients up to summation order.
     `z_clip`: view depth of PyTorch3D >= 0.5's face clipping; None = the reference's rule (znear / 2 = 0.5 when
     perspective_correct — MeshRasterizer only clips for perspective cameras with it on —, else off); 0 = off."""
     if z_clip is None:
@@ -134,6 +136,7 @@ def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backface
     H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
     flags = (_lib.MVR_CULL_BACKFACES if cull_backfaces else 0) | (_lib.MVR_PERSPECTIVE_CORRECT if perspective_correct else 0)
     flags |= _lib.MVR_RASTER_EXACT_ONLY if exact_raster else 0
+    flags |= _lib.MVR_BACKWARD_GATHER if gather_backward else 0
     p = _lib.MeshParams(n_views, H, W, flags, n_light, strip_rows, fov, ambient, diffuse, specular, shininess)
     for k in range(3):
         p.obj_color[k] = float(obj_color[k])

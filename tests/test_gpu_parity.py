@@ -268,6 +268,35 @@ def test_mesh_backward_is_bit_reproducible():
     assert all(t.abs().max() > 0 for t in runs[0])
 
 
+@pytest.mark.parametrize("persp", [True, False])
+def test_mesh_backward_table_kernel_equals_gather_kernel(persp):
+    """k_mesh_backward_tab (per-face data fetched once per strip into an LDS table; the default) against k_mesh_backward
+    (MVR_BACKWARD_GATHER: per-pixel gathers): the same per-pixel arithmetic summed in a different order — gradients
+    agree to float round-off.  Tier M (a single table pass per strip), tier L (~1 pixel per face: several passes, the
+    per-wave pixel queue) and a soup of large faces; per-view light; 224 px and 100 px (a last strip of 4 rows)."""
+    from mvtn_amd import Meshes, PackedMeshes, functional as F
+    vl, fl = _mesh_batch([("M", 5), ("L", 6), ("soup", 7), ("S", 8)])
+    B, V = 4, 5
+    packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl]), _dev())
+    az, el, di = _views(B, V, 9)
+    for size in (224, 100):
+        H = W = size
+        G = torch.randn(B, V, 3, H, W, generator=torch.Generator().manual_seed(5)).to(_dev())
+        grads = {}
+        for mode in ("table", "gather"):
+            params = F.mesh_params(V, size, B * V, (0.9, 0.8, 0.7), (1, 1, 1), perspective_correct=persp, gather_backward=(mode == "gather"))
+            R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+            R, T = R.detach().requires_grad_(True), T.detach().requires_grad_(True)
+            light = F.camera_position_from_spherical_angles(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1))).detach().requires_grad_(True)
+            img = F.render_meshes(packed, R, T, light, params)
+            img.backward(G)
+            grads[mode] = [x.grad.double().cpu().numpy() for x in (R, T, light)]
+        for name, a, b in zip(("R", "T", "light"), grads["table"], grads["gather"]):
+            scale = np.abs(b).max() + 1e-12
+            assert np.abs(a - b).max() / scale < 2e-5, (size, name, np.abs(a - b).max() / scale)
+            assert scale > 1e-3
+
+
 def test_refined_reciprocal_is_correctly_rounded_exhaustive():
     """The rasteriser's perspective-correct barycentrics divide by den through y = RN(1/den) (Markstein); y comes
     from v_rcp_f32 + two Newton steps.  Check y == 1.0f / den (IEEE) for EVERY float in [2^-30, 2^24): all 2^23
