@@ -268,6 +268,30 @@ def test_mesh_backward_is_bit_reproducible():
     assert all(t.abs().max() > 0 for t in runs[0])
 
 
+def test_mesh_backward_at_the_c3_image_size_against_finite_differences(oracle):
+    """C3's image size and mesh tier (224 px, 2 562 vertices / 5 120 faces: ~1 000 covered pixels and ~100 winning faces per
+    8-row strip, the regime k_mesh_backward_tab is built for) against fp64 central differences of the oracle with the
+    pixel -> face map held fixed; relative light, so the camera-position branch of the fused finalize runs too."""
+    from mvtn_amd import MVRenderer, Meshes
+    vl, fl = _mesh_batch([("M", 21), ("M", 22)])
+    B, V, size = 2, 3, 224
+    az, el, di = _views(B, 12, 23)
+    az, el, di = az[:, 2:2 + V], el[:, 2:2 + V], di[:, 2:2 + V]
+    r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="relative").eval()
+    leaves = [_t(x).requires_grad_(True) for x in (az, el, di)]
+    images, _ = r([Meshes([v], [f]) for v, f in zip(vl, fl)], None, *leaves)
+    want = oracle.render_meshes(vl, fl, az, el, di, size, light_dir=oracle.camera_position(az, el, di), obj_color=(0.99999,) * 3,
+                                bg_color=(0.99999,) * 3)
+    assert np.abs(images.detach().cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+    G = np.random.default_rng(24).normal(size=images.shape)
+    images.backward(_t(G))
+    fd = _fd_grad_full(oracle, vl, fl, az, el, di, size, G, want["pix_to_face"], True, True)
+    for name, leaf, ref in zip(("azim", "elev", "dist"), leaves, fd):
+        got = leaf.grad.cpu().numpy().astype(np.float64)
+        rel = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert rel < 2e-3, (name, rel, got, ref)
+
+
 @pytest.mark.parametrize("persp", [True, False])
 def test_mesh_backward_table_kernel_equals_gather_kernel(persp):
     """k_mesh_backward_tab (per-face data fetched once per strip into an LDS table; the default) against k_mesh_backward
