@@ -313,6 +313,44 @@ def main():
             tp = float(t.item())
         pipelined = {"streams": 2, "views_per_s": n_views_total * args.steps / tp, "ms_per_step": tp / args.steps * 1e3}
 
+    # ---- beside `value` (C3): the same training step captured once in a HIP graph (torch.cuda.CUDAGraph) and replayed.
+    # The eager step above costs the host ~0.2 ms of Python / autograd dispatch, about what the GPU needs for it, so
+    # `value` depends on the box's host cores; a replay costs the host one call.  Reported separately, never `value`.
+    graphed = None
+    if args.workload == "mesh_fwdbwd" and not args.host_meshes and not args.no_pipelined:
+        try:
+            ga, ge, gd = (x.detach().clone().requires_grad_(True) for x in (azim, elev, dist_t))   # fresh leaves: the eager
+            # ones carry gradient-accumulation nodes bound to the eager stream
+
+            def gstep():
+                img, _ = renderer(packed, None, ga, ge, gd)
+                return img, torch.autograd.grad(img, (ga, ge, gd), upstream)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    gstep()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g_keep = gstep()
+            for _ in range(min(args.warmup, 50)):
+                graph.replay()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                graph.replay()
+            barrier()
+            tg_ = time.perf_counter() - t0
+            if dist_on:
+                t = torch.tensor([tg_], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tg_ = float(t.item())
+            graphed = {"views_per_s": n_views_total * args.steps / tg_, "ms_per_step": tg_ / args.steps * 1e3}
+            del graph, g_keep
+        except Exception as exc:   # (a capture failure must not lose the measured line)
+            graphed = {"error": str(exc)[:200]}
+
     # ---- optional: the all-gather of rendered views the north_star names (not part of `value`) --------
     gather = None
     if dist_on and not args.no_gather:
@@ -404,6 +442,8 @@ def main():
             line["world_size_seen_by_rccl"] = dist.get_world_size()
         if pipelined:
             line["two_streams"] = pipelined
+        if graphed:
+            line["hip_graph_replay"] = graphed
         sys.stdout.flush()
         try:
             ctypes.CDLL(None).fflush(None)   # C stdio of the libraries (the RCCL banner is buffered there): out to stderr now

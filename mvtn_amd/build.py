@@ -15,7 +15,11 @@ HOSTMATH_PATH = os.path.join(_HERE, "libmvr_hostmath.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                # coverage / depth arithmetic must be the exact IEEE sequence written in mvr_math.h
-               "-ffp-contract=off", "-fno-fast-math"]
+               "-ffp-contract=off", "-fno-fast-math",
+               # the SLP vectoriser pairs scalar f32 operations into v_pk_*_f32 and pays for it in register moves: measured
+               # slower on every kernel it touched (k_mesh_backward_tab 82.8 -> 73.3 us, k_mesh_raster_fast 91.0 -> 88.4 us);
+               # the hand-written two-pixel arithmetic (explicit float2 types) is not affected
+               "-fno-slp-vectorize"]
 
 
 def _stale(target, sources):

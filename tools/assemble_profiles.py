@@ -34,7 +34,7 @@ note = ("separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of `rocprofv3 --pmc X --
         "--no-cpu-baseline [--workload W]` (tools/collect_profiles.sh), averaged per launch; gfx950 correction: FETCH_SIZE doubled "
         "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE calibrated on the points kernel (235200 KiB == its 240 844 800 output bytes)")
 for w, kern, out in (("mesh_fwd", "k_mesh_raster_fast", tag + "_traffic_mesh_fwd.json"), ("points_fwd", "k_points_raster_shade", tag + "_traffic_points_fwd.json"),
-                     ("mesh_fwdbwd", "k_mesh_raster_fast", tag + "_traffic_mesh_fwdbwd.json"), ("mesh_fwdbwd", "k_mesh_backward(", tag + "_traffic_mesh_bwd_kernel.json")):
+                     ("mesh_fwdbwd", "k_mesh_raster_fast", tag + "_traffic_mesh_fwdbwd.json"), ("mesh_fwdbwd", "k_mesh_backward_tab", tag + "_traffic_mesh_bwd_kernel.json")):
     fe = pmc("%s/pmc_FETCH_SIZE_%s" % (src, w), kern)["FETCH_SIZE"]
     wr = pmc("%s/pmc_WRITE_SIZE_%s" % (src, w), kern)["WRITE_SIZE"]
     d = {"kernel": kern.rstrip("("), "FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "hbm_bytes_per_launch": int((2 * fe + wr) * 1024), "note": note}
@@ -43,7 +43,7 @@ for w, kern, out in (("mesh_fwd", "k_mesh_raster_fast", tag + "_traffic_mesh_fwd
 fe = pmc("%s/pmc_FETCH_SIZE_mesh_fwd" % src, "k_mesh_prepass")["FETCH_SIZE"]
 wr = pmc("%s/pmc_WRITE_SIZE_mesh_fwd" % src, "k_mesh_prepass")["WRITE_SIZE"]
 sq = {}
-for kern in ("k_mesh_raster_fast", "k_mesh_backward(", "k_mesh_prepass"):
+for kern in ("k_mesh_raster_fast", "k_mesh_backward_tab", "k_mesh_prepass"):
     v = {}
     v.update(pmc("%s/pmc_sq1_mesh_fwdbwd" % src, kern))
     v.update(pmc("%s/pmc_sq2_mesh_fwdbwd" % src, kern))
