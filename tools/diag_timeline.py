@@ -39,3 +39,9 @@ for a, bb in zip(edges[:-1], edges[1:]):
     mid = 0.5 * (a + bb)
     active = ((st[work] <= mid) & (en[work] >= mid)).sum()
     print("  t = %5.1f us: %4d workgroups in flight" % (mid, active))
+# per XCD (workgroup index & 7): when its last workgroup ends, and the sum of its workgroups' lifetimes
+xcd = (np.arange(nblocks) & 7)[work]
+for x in range(8):
+    m = xcd == x
+    print("  XCD %d: %4d working workgroups, lifetimes sum %.0f us (/128 slots = %.1f us), last end %.1f us, first start %.1f us" % (
+        x, m.sum(), (en[work][m] - st[work][m]).sum(), (en[work][m] - st[work][m]).sum() / 128, en[work][m].max(), st[work][m].min()))
