@@ -13,7 +13,10 @@ from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, synthetic as syn  #
 lib = _lib.load()
 dev = torch.device("cuda:0")
 B, V, H = 16, 12, 224
-vl, fl = zip(*[syn.synthetic_mesh("M", i) for i in range(B)])
+TIER = os.environ.get("MVR_TIER", "M")     # MVR_TIER=L: the C5 shard (8 tier-L meshes x 20 views)
+if TIER == "L":
+    B, V = 8, 20
+vl, fl = zip(*[syn.synthetic_mesh(TIER, i) for i in range(B)])
 packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl]), dev)
 az, el, di = syn.spherical_views(V)
 ta, te, td = (torch.from_numpy(np.tile(x, (B, 1))).to(dev) for x in (az, el, di))
