@@ -1154,6 +1154,42 @@ def test_full_size_c2_all_meshes_against_the_oracle(oracle):
     assert np.abs(img.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
 
 
+def test_prepass_lists_of_very_large_face_counts(oracle):
+    """The pre-pass keeps a thread's first 8 faces in registers and the records of later ones in LDS as far as it has
+    room; a face's first row-bin hands it a 15-bit rank.  Beyond those limits: (a) 40 960 faces over the image and 98 304
+    within a few rows, two views each (the last faces have no LDS record: every bin of theirs takes an atomic in the fill
+    pass); (b) one view of 61 440 faces, all nearer than the origin and inside one strip: >= 32 767 ranked faces in one
+    counter, so the view gets no strip lists and every strip is scanned by the exact path.  Faces are duplicated
+    (coincident: the (z, face index) tie rule decides).  Pixel -> face bit-exact against the oracle."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    v, f = syn.synthetic_mesh("L", 3)
+    size = 64
+    obj = bg = (0.99999,) * 3
+    light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
+    f5 = np.concatenate([f, f[:, [1, 2, 0]], f[::-1], f[:, [2, 0, 1]], f])
+    vs, _ = syn.synthetic_mesh("S", 4)
+    cases = [([v, (v * 0.08 + np.array([0.0, 0.2, 0.0])).astype(np.float32)], [np.concatenate([f, f[::-1]])[:40960], f5[:98304]],
+              _views(2, 2, 31), None),
+             # camera on the +z axis; the object sits between it and the origin, ~6 rows tall, inside the strip of rows 16-23
+             ([(v[:1500] * 0.08 + np.array([0.0, 0.36, 0.6])).astype(np.float32)], [np.random.default_rng(5).integers(0, 1500, (61440, 3))],
+              (np.zeros((1, 1), np.float32), np.zeros((1, 1), np.float32), np.full((1, 1), 2.2, np.float32)), size // 8)]
+    for vl, fl, (az, el, di), want_redo in cases:
+        B, V = az.shape
+        want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, mode=1)
+        packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(x) for x in vl], [torch.from_numpy(np.ascontiguousarray(x)) for x in fl]), _dev())
+        R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+        for exact in (False, True):
+            params = F.mesh_params(V, size, 1, obj, bg, exact_raster=exact)
+            img, p2f, redo = F.render_meshes_fragments(packed, R, T, light, params, return_redo=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(p2f.cpu().numpy(), want["pix_to_face"]), exact
+            assert np.abs(img.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+            if want_redo is not None and not exact:
+                assert int(redo) == want_redo, int(redo)   # no strip lists: every strip of the view went to the exact path
+        assert all((want["pix_to_face"][b * V:(b + 1) * V] >= 0).sum() > 0 for b in range(B))
+
+
 def test_full_size_c4_all_clouds_against_the_oracle(oracle):
     """BASELINE configs[3] at FULL size: 20 clouds x 2048 points x 20 views at 224^2 against the oracle."""
     from mvtn_amd import functional as F
