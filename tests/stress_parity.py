@@ -31,7 +31,7 @@ for case in range(n_cases):
         if kind == 0:
             v, f = syn.cad_soup(int(rng.integers(0, 1000)))
         else:
-            v, f = syn.synthetic_mesh(str(rng.choice(["S", "M"])), int(rng.integers(0, 1000)))
+            v, f = syn.synthetic_mesh(str(rng.choice(["S", "M", "M", "L"])), int(rng.integers(0, 1000)))
         v = v * rng.uniform(0.5, 1.3, 3).astype(np.float32) + rng.uniform(-0.2, 0.2, 3).astype(np.float32)
         vl.append(v.astype(np.float32)); fl.append(f)
     az = rng.uniform(-180, 180, (B, V)).astype(np.float32)
@@ -51,5 +51,21 @@ for case in range(n_cases):
     bad += nd != 0
     print("case %2d: B=%d V=%d size=%3d strip=%d persp=%d cull=%d faces=%s covered=%.2f  map diffs %d  max|d| %.2e%s"
           % (case, B, V, size, strip, persp, cull, [len(f) for f in fl], (p2f >= 0).mean(), nd, err, flag))
-print("cases with coverage mismatches:", bad)
+    # the two backward kernels (face table / per-pixel gathers) on the same case: same arithmetic, different summation order
+    if case % 4 == 0:
+        G = torch.randn(B, V, 3, size, size, generator=torch.Generator().manual_seed(case)).to(dev)
+        grads = []
+        for gather in (False, True):
+            pb = F.mesh_params(V, size, B * V, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip, z_clip=0.0,
+                               gather_backward=gather)
+            Rg, Tg = R.detach().clone().requires_grad_(True), T.detach().clone().requires_grad_(True)
+            Lg = F.camera_position_from_spherical_angles(t(di.reshape(-1)), t(el.reshape(-1)), t(az.reshape(-1))).detach().requires_grad_(True)
+            F.render_meshes(packed, Rg, Tg, Lg, pb).backward(G)
+            grads.append([x.grad.double().cpu().numpy() for x in (Rg, Tg, Lg)])
+        # (+ 1: a soup of coincident double-sided quads has zero vertex normals, its gradients are rounding noise around 0)
+        rel = max(np.abs(a - b).max() / (np.abs(b).max() + 1.0) for a, b in zip(*grads))
+        flagb = "" if rel < 2e-4 else "  <-- BACKWARD KERNELS DISAGREE"
+        bad += rel >= 2e-4
+        print("         backward table vs gather: max relative difference %.1e%s" % (rel, flagb))
+print("cases with mismatches:", bad)
 sys.exit(1 if bad else 0)
