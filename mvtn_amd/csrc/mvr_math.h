@@ -384,6 +384,75 @@ template <typename T> MVR_HD bool face_test(const FaceSetup<T> &fs, T px, T py, 
   return *w0 > (T)0 && *w1 > (T)0 && *w2 > (T)0;
 }
 
+// ---- face clipping at view depth z = zc (PyTorch3D >= 0.5 clip_faces, SURVEY A.9 ii; perspective-correct rasterisation) ------
+// A face with one or two vertices nearer than zc is cut: one vertex behind (p1; p2, p3 the next two in cyclic order) leaves
+// the quad (p4, p2, p5) + (p5, p2, p3), two behind (p1 the one in front) leave (p1, p4, p5); p4 on edge p1 p2, p5 on p1 p3 at
+// the view-depth parameter w = (z1 - zc) / (z1 - z_other); their NDC x, y are interpolated in x z, y z (linear in view space)
+// and divided by zc.  The rasteriser tests the cut triangles; PyTorch3D maps their barycentrics back to the original face
+// (beta).  Same operations in the same order as the oracle's clip_face.  straddles(): 1 or 2 vertices behind.
+template <typename T> MVR_HD bool straddles(T z0, T z1, T z2, T zc) {
+  const int nb = (z0 < zc ? 1 : 0) + (z1 < zc ? 1 : 0) + (z2 < zc ? 1 : 0);
+  return nb == 1 || nb == 2;
+}
+// (No dynamically indexed arrays: private arrays that the compiler cannot keep in registers would give every kernel that
+// contains this rare path a scratch allocation.  The barycentric map `beta` of the reference is not needed here: colours
+// and gradients of cut faces use bary_ray below.)
+template <typename T> struct ClippedFace { int nt; V3<T> t0[3], t1[3]; };   // nt cut triangles: t0 (and t1)
+template <typename T> MVR_HD ClippedFace<T> clip_face(const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, T zc) {
+  ClippedFace<T> o;
+  const bool h0 = v0.z < zc, h1 = v1.z < zc, h2 = v2.z < zc;   // behind the plane
+  const int nb = (h0 ? 1 : 0) + (h1 ? 1 : 0) + (h2 ? 1 : 0);
+  o.t0[0] = v0; o.t0[1] = v1; o.t0[2] = v2;
+  o.t1[0] = v0; o.t1[1] = v1; o.t1[2] = v2;
+  o.nt = nb == 3 ? 0 : 1;
+  if (nb == 0 || nb == 3) return o;
+  // i1: the vertex that is alone on its side of the plane (the LAST such index, as the reference's loop leaves it);
+  // p1, p2, p3: the vertices from there in cyclic order
+  const bool alone = nb == 1;
+  const int i1 = (h2 == alone) ? 2 : ((h1 == alone) ? 1 : 0);
+  const V3<T> p1 = i1 == 0 ? v0 : (i1 == 1 ? v1 : v2), p2 = i1 == 0 ? v1 : (i1 == 1 ? v2 : v0), p3 = i1 == 0 ? v2 : (i1 == 1 ? v0 : v1);
+  const T w2 = (p1.z - zc) / (p1.z - p2.z), w3 = (p1.z - zc) / (p1.z - p3.z);
+  V3<T> p4, p5;
+  p4.x = ((p1.x * p1.z) * ((T)1 - w2) + (p2.x * p2.z) * w2) / zc;
+  p5.x = ((p1.x * p1.z) * ((T)1 - w3) + (p3.x * p3.z) * w3) / zc;
+  p4.y = ((p1.y * p1.z) * ((T)1 - w2) + (p2.y * p2.z) * w2) / zc;
+  p5.y = ((p1.y * p1.z) * ((T)1 - w3) + (p3.y * p3.z) * w3) / zc;
+  p4.z = zc; p5.z = zc;
+  if (nb == 1) {   // p1 behind: (p4, p2, p5) and (p5, p2, p3)
+    o.t0[0] = p4; o.t0[1] = p2; o.t0[2] = p5;
+    o.t1[0] = p5; o.t1[1] = p2; o.t1[2] = p3;
+    o.nt = 2;
+  } else {         // p2, p3 behind: (p1, p4, p5)
+    o.t0[0] = p1; o.t0[1] = p4; o.t0[2] = p5;
+    o.nt = 1;
+  }
+  return o;
+}
+
+// Barycentrics of the point where the ray of pixel (px, py) meets the plane of a triangle given in VIEW space (camera at the
+// origin, ray direction d = (px / s, py / s, 1)): b_i = c_i / sum c, c_0 = d . (X1 x X2), c_1 = d . (X2 x X0), c_2 = d . (X0 x X1).
+// In exact arithmetic these are the perspective-correct barycentrics of the rasteriser, and the ones PyTorch3D's clipped
+// faces map back to — without dividing by a vertex depth, so they stay finite for vertices at or behind the camera plane.
+// Shading and gradients of pixels on CUT faces use them (colours and gradients only: coverage and depth come from the
+// cut triangles, bit for bit as in the oracle).
+template <typename T> MVR_HD void bary_ray(const V3<T> &d, const V3<T> &X0, const V3<T> &X1, const V3<T> &X2, T *b0, T *b1, T *b2, T *inv_sum = nullptr) {
+  const T c0 = dot(d, cross(X1, X2)), c1 = dot(d, cross(X2, X0)), c2 = dot(d, cross(X0, X1));
+  const T r = (T)1 / ((c0 + c1) + c2);
+  *b0 = c0 * r; *b1 = c1 * r; *b2 = c2 * r;
+  if (inv_sum) *inv_sum = r;
+}
+// gradient of bary_ray w.r.t. the three view-space vertices, given g_i = dL/db_i
+template <typename T> MVR_HD void bary_ray_bwd(const V3<T> &d, const V3<T> &X0, const V3<T> &X1, const V3<T> &X2, T b0, T b1, T b2, T inv_sum,
+                                               T g0, T g1, T g2, V3<T> *gX0, V3<T> *gX1, V3<T> *gX2) {
+  const T gs = (g0 * b0 + g1 * b1) + g2 * b2;
+  const T h0 = (g0 - gs) * inv_sum, h1 = (g1 - gs) * inv_sum, h2 = (g2 - gs) * inv_sum;   // dL/dc_i
+  // c0 = d.(X1 x X2) = X1.(X2 x d) = X2.(d x X1); c1 = d.(X2 x X0) = X2.(X0 x d) = X0.(d x X2); c2 = d.(X0 x X1) = X0.(X1 x d) = X1.(d x X0)
+  const V3<T> dX0 = cross(d, X0), dX1 = cross(d, X1), dX2 = cross(d, X2);
+  *gX0 = {h1 * dX2.x - h2 * dX1.x, h1 * dX2.y - h2 * dX1.y, h1 * dX2.z - h2 * dX1.z};
+  *gX1 = {h2 * dX0.x - h0 * dX2.x, h2 * dX0.y - h0 * dX2.y, h2 * dX0.z - h0 * dX2.z};
+  *gX2 = {h0 * dX1.x - h1 * dX0.x, h0 * dX1.y - h1 * dX0.y, h0 * dX1.z - h1 * dX0.z};
+}
+
 // ---- shading: HardPhongShader + DirectionalLights (models/renderer.py:102-103,190-191) ----
 
 template <typename T> struct Phong { T ambient, diffuse, specular, shininess; };

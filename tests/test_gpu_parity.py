@@ -1129,7 +1129,7 @@ def test_fast_rasteriser_equals_exact_kernel(name, specs, V, size, dist, jitter)
     print("%s: %d of %d strips fell back to the exact rasteriser" % (name, out["fast"][2], n_strips))
     assert np.array_equal(out["fast"][1], out["exact"][1]), "%d pixels differ" % int((out["fast"][1] != out["exact"][1]).sum())
     assert np.abs(out["fast"][0] - out["exact"][0]).max() <= 5e-5
-    if "soup" not in str(specs) and dist >= 1.2:
+    if "soup" not in str(specs) and dist >= 1.6:   # (nearer than 1.5 the clip plane z = 0.5 cuts faces: those views take the exact path)
         assert out["fast"][2] <= n_strips // 100, "ordinary meshes should almost never need the exact path"
     if "soup" in str(specs):
         assert out["fast"][2] > 0, "coincident double-sided faces must be undecidable for the fast path"
@@ -1252,55 +1252,43 @@ def test_custom_vertex_colours_with_a_packed_batch(oracle):
     assert float((img_packed - 0.99999).abs().max()) > 0.05      # not a white render
 
 
-def test_z_clip_culls_like_the_reference_and_counts_straddling_faces(oracle):
+@pytest.mark.parametrize("exact", [False, True])
+def test_z_clip_cuts_faces_like_the_reference(oracle, exact):
     """PyTorch3D >= 0.5 clips faces at view depth znear / 2 = 0.5 (SURVEY A.9 ii; active as soon as transform_distance
-    lets dist drop towards 1.1, models/mvtn.py:33,68,109).  The library applies the cull half of that rule exactly
-    (faces wholly nearer than the plane disappear) and counts the faces that straddle the plane, which it rasterises
-    whole: (a) at dist 2.2 nothing straddles and the images ARE the clipping reference's; (b) at dist 1.1 the image is
-    bit-exactly "oracle without clipping on the mesh minus the wholly-near faces", and the straddler count equals the
-    oracle's; (c) z_clip = 0 switches the rule off."""
+    lets dist drop towards 1.1, models/mvtn.py:33,68,109): faces wholly nearer than the plane disappear, faces that
+    straddle it are cut into one or two triangles.  Against the oracle's clip_faces restatement: pixel -> face map
+    bit-exact and images within tolerance at dist 2.2 (nothing to cut), 1.1 and 0.9 (camera inside the bounding sphere:
+    vertices behind the camera, faces cut on both sides), with and without back-face culling, through the default
+    forward (views with cut faces fall back to the exact kernel per strip) and the exact-only kernel; the count of cut
+    faces equals the oracle's; z_clip = 0 switches the rule off."""
     from mvtn_amd import functional as F
     from mvtn_amd.structures import Meshes, PackedMeshes
-    vl, fl = _mesh_batch([("M", 0), ("S", 4)])
-    B, V, size = 2, 4, 96
+    vl, fl = _mesh_batch([("M", 0), ("S", 4), ("soup", 2)])
+    B, V, size = 3, 4, 96
     az, el, _ = _views(B, 4, 3)
     obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
     light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
     packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
-    for dist, expect_straddlers in ((2.2, False), (1.1, True)):
+    for dist, cull, expect_cut in ((2.2, False, False), (1.1, False, True), (1.1, True, True), (0.9, False, True)):
         di = np.full((B, V), dist, np.float32)
         R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
-        params = F.mesh_params(V, size, 1, obj, bg)                       # z_clip = None -> 0.5 (perspective_correct)
+        params = F.mesh_params(V, size, 1, obj, bg, cull_backfaces=cull, exact_raster=exact)   # z_clip = None -> 0.5 (perspective_correct)
         assert abs(params.z_clip - 0.5) < 1e-12
         img, p2f, ns = F.render_meshes_fragments(packed, R, T, light, params, return_straddlers=True)
-        clipref = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, z_clip=0.5)
-        assert int(ns.item()) == int(clipref["straddlers"].sum())
-        assert (int(ns.item()) > 0) == expect_straddlers
+        want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, z_clip=0.5, cull_backfaces=cull, mode=1)
+        assert int(ns.item()) == int(want["straddlers"].sum())
+        assert (int(ns.item()) > 0) == expect_cut
         p2f, img = p2f.cpu().numpy(), img.cpu().numpy()
-        if not expect_straddlers:
-            assert np.array_equal(p2f, clipref["pix_to_face"]) and np.abs(img - clipref["images"]).max() <= TOL_PIXEL
-            continue
-        # expected images: per view, the no-clipping render of the mesh without the faces wholly nearer than the plane
-        Ro, To = oracle.look_at(az, el, di)
-        n_culled = 0
-        for b in range(B):
-            for v in range(V):
-                n = b * V + v
-                zv = (vl[b].astype(np.float32) @ Ro[n] + To[n])[:, 2]
-                keep = ~(zv[fl[b]] < np.float32(0.5)).all(1)
-                n_culled += int((~keep).sum())
-                idx = np.nonzero(keep)[0]
-                w = oracle.render_meshes([vl[b]], [fl[b][keep]], az[b:b + 1, v:v + 1], el[b:b + 1, v:v + 1], di[b:b + 1, v:v + 1],
-                                         size, obj_color=obj, bg_color=bg, z_clip=0.0)
-                # vertex normals are a property of the WHOLE mesh: compare coverage only (faces renumbered back)
-                wp = w["pix_to_face"][0]
-                wp = np.where(wp >= 0, idx[np.maximum(wp, 0)], -1)
-                assert np.array_equal(p2f[n], wp), (dist, n, int((p2f[n] != wp).sum()))
-        assert n_culled > 0
-        off = F.mesh_params(V, size, 1, obj, bg, z_clip=0.0)
-        img0, p2f0, ns0 = F.render_meshes_fragments(packed, R, T, light, off, return_straddlers=True)
-        legacy = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, z_clip=0.0)
-        assert int(ns0.item()) == 0 and np.array_equal(p2f0.cpu().numpy(), legacy["pix_to_face"])
+        assert np.array_equal(p2f, want["pix_to_face"]), (dist, cull, int((p2f != want["pix_to_face"]).sum()))
+        well = _well_conditioned_pixels(vl, fl, want["pix_to_face"], V)
+        diff = np.abs(img - want["images"]).reshape(B * V, 3, size, size).max(1)
+        assert float(diff[well].max()) <= TOL_PIXEL, (dist, cull, float(diff[well].max()))
+        if expect_cut:   # and the rule can be switched off
+            off = F.mesh_params(V, size, 1, obj, bg, cull_backfaces=cull, z_clip=0.0, exact_raster=exact)
+            img0, p2f0, ns0 = F.render_meshes_fragments(packed, R, T, light, off, return_straddlers=True)
+            legacy = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, z_clip=0.0, cull_backfaces=cull, mode=1)
+            assert int(ns0.item()) == 0 and np.array_equal(p2f0.cpu().numpy(), legacy["pix_to_face"])
+            assert not np.array_equal(legacy["pix_to_face"], want["pix_to_face"])
 
 
 def test_regularize_views_reproduces_the_reference_fixture():
