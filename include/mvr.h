@@ -81,9 +81,10 @@ typedef struct mvr_mesh_params {
   float obj_color[3];     /* rendering_color(), models/renderer.py:153-160 */
   float bg_color[3];      /* BlendParams(background_color), :102 */
   float z_clip;           /* PyTorch3D >= 0.5 clips faces at view depth znear / 2 = 0.5 for the perspective cameras of this
-                             path (MeshRasterizer: z_clip_value); 0 = no clipping (PyTorch3D < 0.5).  Faces wholly nearer
-                             than the plane are culled as the reference does; faces that STRADDLE it are rasterised whole
-                             and counted (mvr_mesh_clip_straddlers): a forward is clip-exact iff that count is 0 */
+                             path (MeshRasterizer: z_clip_value) when the rasterisation is perspective-correct; 0 = no
+                             clipping (PyTorch3D < 0.5).  Faces wholly nearer than the plane are culled, faces that
+                             STRADDLE it are cut into one or two triangles (pytorch3d/renderer/mesh/clip.py); > 0 needs
+                             MVR_PERSPECTIVE_CORRECT.  (The soft path culls, but draws straddling faces whole.) */
 } mvr_mesh_params;
 
 typedef struct mvr_points_params {
@@ -206,9 +207,10 @@ int mvr_render_meshes_soft_backward(const mvr_mesh_batch *meshes, const mvr_mesh
 /* Scratch the mesh calls need (vertex attributes, projected vertices, backward partials). */
 size_t mvr_mesh_workspace_bytes(const mvr_mesh_batch *meshes, const mvr_mesh_params *params);
 
-/* How many faces of the LAST forward that used `workspace` straddled the z-clip plane (summed over the views): they were
- * rasterised unclipped, i.e. as PyTorch3D < 0.5 would.  0 (always, for unit-normalised objects at distance >= 1.5):
- * the images are what the clipping reference renders.  count: 1 device int. */
+/* How many faces of the LAST forward that used `workspace` straddled the z-clip plane and were cut there (summed over the
+ * views; 0 for unit-normalised objects at distance >= 1.5).  Views with such faces take the exact rasteriser.  In the soft
+ * path they are rasterised whole (as PyTorch3D < 0.5 does): there the count tells whether a forward was clip-exact.
+ * count: 1 device int. */
 int mvr_mesh_clip_straddlers(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const void *workspace, size_t workspace_bytes,
                              int32_t *count, mvr_stream_t stream);
 

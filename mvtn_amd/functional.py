@@ -291,7 +291,7 @@ def render_mesh_views(packed: PackedMeshes, azim, elev, dist, light_dir, params,
 def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params, return_redo=False, return_straddlers=False):
     """(images, pix_to_face (N,H,W) int32 LOCAL face index / -1) without autograd — for parity tests.
     `return_redo`: also the number of (view, strip) tiles the fast rasteriser left to the exact kernel (a device int);
-    `return_straddlers`: also the number of faces that straddled the z-clip plane (rasterised unclipped)."""
+    `return_straddlers`: also the number of faces that straddled the z-clip plane (and were cut there)."""
     lib = _lib.load()
     R, T, light = _f32c(R), _f32c(T), _f32c(light_dir)
     _require_cuda(R, T, light, packed.verts)

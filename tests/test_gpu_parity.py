@@ -167,14 +167,14 @@ def test_mesh_custom_vertex_colors(oracle):
     assert np.abs(img.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
 
 
-def _fd_grad_full(oracle, vl, fl, az, el, di, size, G, p2f, relative, persp, h=1e-5):
+def _fd_grad_full(oracle, vl, fl, az, el, di, size, G, p2f, relative, persp, h=1e-5, z_clip=0.0):
     """fp64 central differences of L = sum(G * image) w.r.t. (azim, elev, dist), pix_to_face fixed."""
     vl64 = [v.astype(np.float64) for v in vl]
 
     def L(a, e, d):
         ld = oracle.camera_position(a, e, d, np.float64) if relative else np.array([[0.0, 1.0, 0.0]])
         o = oracle.render_meshes(vl64, fl, a, e, d, size, light_dir=ld, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3,
-                                 perspective_correct=persp, dtype=np.float64, fixed_p2f=p2f, return_fragments=False)
+                                 perspective_correct=persp, dtype=np.float64, fixed_p2f=p2f, return_fragments=False, z_clip=z_clip)
         return float((o["images"] * G).sum())
 
     base = [az.astype(np.float64), el.astype(np.float64), di.astype(np.float64)]
@@ -266,6 +266,36 @@ def test_mesh_backward_is_bit_reproducible():
         for a, b in zip(runs[0], other):
             assert torch.equal(a, b)
     assert all(t.abs().max() > 0 for t in runs[0])
+
+
+@pytest.mark.parametrize("dist,gather", [(1.1, False), (1.1, True), (0.9, False), (0.9, True)])
+def test_mesh_backward_through_cut_faces_against_finite_differences(oracle, dist, gather):
+    """Gradients where the clip plane cuts faces (dist 1.1: vertices between the camera plane and z = 0.5; dist 0.9: the
+    camera is inside the bounding sphere, vertices behind it): fp64 central differences of the CLIPPING oracle with the
+    pixel -> face map held fixed, both backward kernels."""
+    from mvtn_amd import Meshes, PackedMeshes, functional as F
+    vl, fl = _mesh_batch([("M", 31)])
+    B, V, size = 1, 3, 64
+    az, el, _ = _views(B, 4, 33)
+    az, el = az[:, :V], el[:, :V]
+    di = np.full((B, V), dist, np.float32)
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    obj = bg = (0.99999,) * 3
+    params = F.mesh_params(V, size, B * V, obj, bg, gather_backward=gather)   # z_clip 0.5
+    leaves = [_t(x.reshape(-1)).requires_grad_(True) for x in (az, el, di)]
+    R, T = F.look_at_view_transform(leaves[2], leaves[1], leaves[0])
+    light = F.camera_position_from_spherical_angles(leaves[2], leaves[1], leaves[0])
+    images = F.render_meshes(packed, R, T, light, params)
+    want = oracle.render_meshes(vl, fl, az, el, di, size, light_dir=oracle.camera_position(az, el, di), obj_color=obj, bg_color=bg, z_clip=0.5)
+    assert int(want["straddlers"].sum()) > 0
+    assert np.abs(images.detach().cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+    G = np.random.default_rng(34).normal(size=images.shape)
+    images.backward(_t(G))
+    fd = _fd_grad_full(oracle, vl, fl, az, el, di, size, G, want["pix_to_face"], True, True, z_clip=0.5)
+    for name, leaf, ref in zip(("azim", "elev", "dist"), leaves, fd):
+        got = leaf.grad.cpu().numpy().astype(np.float64).reshape(ref.shape)
+        rel = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert rel < 2e-3, (name, rel, got, ref)
 
 
 def test_mesh_backward_at_the_c3_image_size_against_finite_differences(oracle):
