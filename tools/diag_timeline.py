@@ -45,3 +45,29 @@ for x in range(8):
     m = xcd == x
     print("  XCD %d: %4d working workgroups, lifetimes sum %.0f us (/128 slots = %.1f us), last end %.1f us, first start %.1f us" % (
         x, m.sum(), (en[work][m] - st[work][m]).sum(), (en[work][m] - st[work][m]).sum() / 128, en[work][m].max(), st[work][m].min()))
+# what an ideal longest-first schedule of the measured workgroup lifetimes would take on each XCD's 128 slots
+import heapq
+for x in range(8):
+    m = xcd == x
+    dur = np.sort((en[work][m] - st[work][m]))[::-1]
+    slots = [0.0] * 128
+    heapq.heapify(slots)
+    for d_ in dur:
+        heapq.heappush(slots, heapq.heappop(slots) + d_)
+    print("  XCD %d: longest-first makespan of the measured lifetimes %.1f us (sum / 128 = %.1f, measured last end %.1f)" % (
+        x, max(slots), dur.sum() / 128, en[work][m].max()))
+# list scheduling (next workgroup to the first free slot) of the measured lifetimes in three orders: as dispatched now
+# (centre strips first), by the strip's listed faces (known after the pre-pass), by the lifetime itself (ideal)
+gln = d[:, 6].astype(np.float64)
+allidx = np.arange(nblocks)
+def makespan(order):
+    slots = [0.0] * 128
+    heapq.heapify(slots)
+    for i in order:
+        heapq.heappush(slots, heapq.heappop(slots) + (en[i] - st[i] if work[i] else 0.05))
+    return max(slots)
+for x in range(8):
+    idx = allidx[(allidx & 7) == x]
+    life = np.where(work[idx], en[idx] - st[idx], 0.0)
+    print("  XCD %d: simulated makespan: dispatch order %.1f us, by listed faces %.1f us, by lifetime %.1f us" % (
+        x, makespan(idx), makespan(idx[np.argsort(-gln[idx], kind="stable")]), makespan(idx[np.argsort(-life, kind="stable")])))
