@@ -49,8 +49,13 @@ enum {
                                     matching mvr_render_meshes_forward call used -> its vertex normals are reused */
   MVR_RASTER_EXACT_ONLY = 8,   /* forward only: skip the fast rasteriser (exact coverage + provably ordered affine inverse
                                   depth) and run every strip through the exact-arithmetic kernel; same images, slower */
-  MVR_BACKWARD_GATHER = 16     /* backward only: skip the face-table kernel (per-face data fetched once per strip into LDS)
+  MVR_BACKWARD_GATHER = 16,    /* backward only: skip the face-table kernel (per-face data fetched once per strip into LDS)
                                   and gather per covered pixel; same gradients up to summation order, slower */
+  MVR_KEEP_PIXEL_LISTS = 32    /* forward with pix_to_face: also leave, per (view, strip), the list of covered pixels with
+                                  their winners' slots and the winners' faces in the workspace (the rasteriser has them at
+                                  hand); a backward given the same workspace with MVR_WORKSPACE_FROM_FORWARD and this flag
+                                  starts from them instead of re-deriving them from pix_to_face.  The workspace is larger
+                                  with this flag (mvr_mesh_workspace_bytes): pass it to BOTH calls or to neither */
 };
 
 /* A batch of B triangle meshes packed back to back (what models/renderer.py:66-77 builds

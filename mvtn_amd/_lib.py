@@ -15,6 +15,7 @@ MVR_PERSPECTIVE_CORRECT = 2
 MVR_WORKSPACE_FROM_FORWARD = 4
 MVR_RASTER_EXACT_ONLY = 8
 MVR_BACKWARD_GATHER = 16
+MVR_KEEP_PIXEL_LISTS = 32
 MVR_SHADER_SOFT_PHONG, MVR_SHADER_SOFT_SILHOUETTE = 0, 1
 
 

@@ -157,6 +157,9 @@ class _RenderMeshes(torch.autograd.Function):
             raise ValueError("R/T must have B*V = %d rows" % N)
         dev = R.device
         mb = packed.c_struct()
+        if need_grad:   # the rasteriser leaves its lists of covered pixels / winning faces for the backward
+            params = _lib.MeshParams.from_buffer_copy(params)
+            params.flags |= _lib.MVR_KEEP_PIXEL_LISTS
         ws_bytes = lib.mvr_mesh_workspace_bytes(mb, params)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=dev)
@@ -222,6 +225,9 @@ class _RenderMeshViews(torch.autograd.Function):
             light = _f32c(light)
         sp = status.data_ptr() if host_status is None else host_status.data_ptr()
         mb = packed.c_struct()
+        if need_grad:   # the rasteriser leaves its lists of covered pixels / winning faces for the backward
+            params = _lib.MeshParams.from_buffer_copy(params)
+            params.flags |= _lib.MVR_KEEP_PIXEL_LISTS
         ws_bytes = packed.workspace_bytes(params)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=dev)

@@ -196,7 +196,7 @@ class PackedMeshes:
 
     def workspace_bytes(self, params):
         """mvr_mesh_workspace_bytes for this batch, remembered per (views, image, strip) shape."""
-        key = (params.n_views, params.image_h, params.image_w, params.strip_rows)
+        key = (params.n_views, params.image_h, params.image_w, params.strip_rows, params.flags & _lib.MVR_KEEP_PIXEL_LISTS)
         cache = self.__dict__.setdefault("_ws_bytes", {})
         n = cache.get(key)
         if n is None:
