@@ -7,15 +7,20 @@
 //     k_mesh_prepass       : workgroups [0, B): world-space vertex normals once per MESH (64-bit fixed-point LDS sums);
 //                            workgroups [B, B+N): one VIEW each: look-at of all views (R, T, validity, device-side
 //                            remedy, relative-light camera positions), project the vertices (16 B records, L2 resident),
-//                            2-byte row-bin range per face, per-strip face lists (near faces first), shading constants
-//     k_mesh_raster_shade  : one workgroup per (view, strip of 8 rows), heaviest strips first:
-//         list -> setup (one lane per face: exact candidate range, signed coefficient record in LDS) -> balanced
-//         split of the batch's pixel PAIRS over the lanes -> packed-f32 exact inside test / barycentrics / depth ->
-//         64-bit LDS atomicMin on (float_bits(z) << 32 | face) — exactly PyTorch3D's (z, face index) order;
-//         far faces are rejected against per-tile depth bounds left by the near ones (hierarchical z);
-//         covered pixels are compacted and shaded (Phong + hard blend), planar (B,V,3,H,W) stores.
+//                            one LDS word per vertex (row range + depth flags), 2-byte row-bin range per face, per-strip
+//                            face lists (near faces first; faces cut by the z-clip plane marked), shading constants
+//     k_mesh_raster_fast   : one workgroup per (view, strip of 8 rows), heaviest strips first (mvr_mesh_raster_fast.inc):
+//         coverage from the SIGNS of the exact edge functions, depth order from an affine inverse depth whose order is
+//         proven per pixel (64-bit LDS atomicMax with the previous occupant returned); what it cannot prove — a few pixels
+//         per frame — is settled by the reference's exact test in the same launch, a strip it cannot take at all (coincident
+//         faces, faces to cut) by the exact body below; winners' shading planes in an LDS table, planar (B,V,3,H,W) stores.
+//     k_mesh_raster_shade  : the exact-arithmetic rasteriser (round 1; MVR_RASTER_EXACT_ONLY, per-vertex colours, and the
+//         body the fast kernel's workgroups fall back to): packed-f32 exact inside test / barycentrics / depth, 64-bit LDS
+//         atomicMin on (float_bits(z) << 32 | face) — exactly PyTorch3D's (z, face index) order; cuts faces at the clip plane.
 //     No per-pixel fragment tensors, no bin tables, no V-fold mesh copies ever touch HBM.
-//   mesh backward = k_mesh_backward (per covered pixel, 18 partial sums per workgroup) + one finalize launch
+//   mesh backward = k_mesh_backward_tab (per-face data once per strip in an LDS table, 18 partial sums per workgroup; starts
+//                   from the forward's pixel lists when it has them) [k_mesh_backward: per-pixel gathers] + one finalize launch
+//   soft shaders  = k_mesh_soft_forward / _backward (top-K fragments, softmax / sigmoid blend, coverage gradient)
 //   points        = k_points_prepass (look-at + projection; k_points_project when R, T are given) + k_points_raster_shade
 //                   (hits compacted, 16-byte stores) [k_points_raster_topk for points_per_pixel > 1]
 //
