@@ -136,6 +136,34 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.mvr_mesh_workspace_bytes(None, None) == 0
 
 
+def test_flag_constants_and_workspace_rules_without_gpu():
+    """The Python mirror of the mvr_mesh_params flags equals the header's enum; MVR_KEEP_PIXEL_LISTS enlarges the workspace
+    (and only appends to it); z_clip > 0 without perspective-correct rasterisation is rejected (PyTorch3D never clips
+    then) — all before any HIP call."""
+    from mvtn_amd import _lib, functional as F
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "mvr.h")).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"\b(MVR_[A-Z_]+)\s*=\s*(\d+)", header))
+    for name in ("MVR_CULL_BACKFACES", "MVR_PERSPECTIVE_CORRECT", "MVR_WORKSPACE_FROM_FORWARD", "MVR_RASTER_EXACT_ONLY",
+                 "MVR_BACKWARD_GATHER", "MVR_KEEP_PIXEL_LISTS"):
+        assert getattr(_lib, name) == enum[name], name
+    flags = [enum[k] for k in ("MVR_CULL_BACKFACES", "MVR_PERSPECTIVE_CORRECT", "MVR_WORKSPACE_FROM_FORWARD", "MVR_RASTER_EXACT_ONLY",
+                               "MVR_BACKWARD_GATHER", "MVR_KEEP_PIXEL_LISTS")]
+    assert sorted(flags) == [1, 2, 4, 8, 16, 32]
+    mb = _lib.MeshBatch(2, 200, 400, 200, 100, 0, 1, 1, 1, 1, None)   # (pointers only have to be non-null for the size query)
+    base = F.mesh_params(12, 224, 1, (1, 1, 1), (1, 1, 1))
+    keep = _lib.MeshParams.from_buffer_copy(base)
+    keep.flags |= _lib.MVR_KEEP_PIXEL_LISTS
+    n0, n1 = lib.mvr_mesh_workspace_bytes(mb, base), lib.mvr_mesh_workspace_bytes(mb, keep)
+    n_strips, cap = 224 // 8, 8 * 224
+    assert n1 >= n0 + 24 * n_strips * (8 + cap * 6) and n1 <= n0 + 24 * n_strips * (8 + cap * 6) + 3 * 256
+    bad = F.mesh_params(12, 224, 1, (1, 1, 1), (1, 1, 1), perspective_correct=False, z_clip=0.5)
+    assert lib.mvr_render_meshes_forward(mb, bad, 1, 1, 1, 1, None, 1, 1 << 40, None) == 1
+    assert b"z_clip" in lib.mvr_last_error()
+    assert F.mesh_params(12, 224, 1, (1, 1, 1), (1, 1, 1), perspective_correct=False).z_clip == 0.0   # the default follows the reference's rule
+    assert abs(F.mesh_params(12, 224, 1, (1, 1, 1), (1, 1, 1)).z_clip - 0.5) < 1e-12
+
+
 def test_product_has_no_cpu_fallback_and_never_imports_the_oracle():
     import mvtn_amd
     from mvtn_amd import MVRenderer
