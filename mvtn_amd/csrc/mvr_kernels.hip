@@ -52,6 +52,7 @@ typedef V3<float> f3;
 #define MVR_RB 256               // threads per rasteriser workgroup
 #endif
 #define MVR_RW (MVR_RB / 64)
+static_assert(MVR_RB == 256, "the rasterisers' LDS layouts and their host-side sizes assume 4 waves per workgroup (128 / 512 measured: wrong results / faults)");
 #define MVR_RBATCH MVR_RB        // faces set up per batch: one per lane
 #ifndef MVR_PTS_LIST_INTS
 #define MVR_PTS_LIST_INTS 2048   // point-kernel hit list (one chunk of 2048 points can hit entirely)
