@@ -49,6 +49,10 @@ for kern in ("k_mesh_raster_fast", "k_mesh_backward_tab", "k_mesh_prepass"):
     v.update(pmc("%s/pmc_sq2_mesh_fwdbwd" % src, kern))
     v.update(pmc("%s/pmc_sq3_mesh_fwdbwd" % src, kern))
     sq[kern.rstrip("(")] = v
+# the forward rasteriser as the inference step (C2) runs it; the entry above is the training step's (it also writes the pixel lists)
+if glob.glob("%s/pmc_sq1_mesh_fwd/**/*counter_collection.csv" % src, recursive=True):
+    sq["k_mesh_raster_fast (training step)"] = sq["k_mesh_raster_fast"]
+    sq["k_mesh_raster_fast"] = pmc("%s/pmc_sq1_mesh_fwd" % src, "k_mesh_raster_fast")
 sq["k_points_raster_shade"] = pmc("%s/pmc_sq1_points_fwd" % src, "k_points_raster_shade")
 sq["_note"] = ("rocprofv3 --pmc passes of tools/collect_profiles.sh (C3 step for the mesh kernels, C4 for the points kernel); SQ_*_CYCLES / "
                "SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles summed over waves, SQ_BUSY_CYCLES = 32 x kernel cycles")

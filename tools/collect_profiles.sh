@@ -16,6 +16,8 @@ done
 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_sq1_mesh_fwdbwd -- python3 bench.py --workload mesh_fwdbwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $out/pmc_sq2_mesh_fwdbwd -- python3 bench.py --workload mesh_fwdbwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_ATOMIC_RETURN SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL --output-format csv -d $out/pmc_sq3_mesh_fwdbwd -- python3 bench.py --workload mesh_fwdbwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+# (the forward rasteriser of the INFERENCE step: in the training step above it also writes the pixel lists)
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_sq1_mesh_fwd -- python3 bench.py --workload mesh_fwd --steps 3 --warmup 2 --no-cpu-baseline --no-pipelined > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_sq1_points_fwd -- python3 bench.py --workload points_fwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 find $out -name "*kernel_trace.csv" -delete
 find $out -name "*agent_info.csv" -delete
