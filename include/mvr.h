@@ -90,6 +90,9 @@ typedef struct mvr_mesh_params {
                              clipping (PyTorch3D < 0.5).  Faces wholly nearer than the plane are culled, faces that
                              STRADDLE it are cut into one or two triangles (pytorch3d/renderer/mesh/clip.py); > 0 needs
                              MVR_PERSPECTIVE_CORRECT.  (The soft path culls, but draws straddling faces whole.) */
+  float out_mean[3];      /* the trainer's Normalize (viewGCN/tools/Trainer_mvt.py:41-49) in the rasteriser's stores: the images */
+  float out_std[3];       /* come out as (rgb - out_mean) / out_std per channel, the backward takes the gradient of THAT;
+                             out_std[c] == 0 (a zeroed struct): channel c is stored as rendered.  Hard path only */
 } mvr_mesh_params;
 
 typedef struct mvr_points_params {

@@ -30,7 +30,8 @@ class MeshParams(ctypes.Structure):  # struct mvr_mesh_params
                 ("flags", ctypes.c_int32), ("n_light", ctypes.c_int32), ("strip_rows", ctypes.c_int32),
                 ("fov_deg", ctypes.c_float), ("ambient", ctypes.c_float), ("diffuse", ctypes.c_float),
                 ("specular", ctypes.c_float), ("shininess", ctypes.c_float),
-                ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3), ("z_clip", ctypes.c_float)]
+                ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3), ("z_clip", ctypes.c_float),
+                ("out_mean", ctypes.c_float * 3), ("out_std", ctypes.c_float * 3)]
 
 
 class SoftParams(ctypes.Structure):  # struct mvr_soft_params

@@ -126,9 +126,11 @@ def camera_position_from_spherical_angles(distance, elevation, azimuth):
 
 def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backfaces=False, perspective_correct=True,
                 fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, strip_rows=0, exact_raster=False, z_clip=None,
-                gather_backward=False):
+                gather_backward=False, normalize=None):
     """`exact_raster`: skip the fast rasteriser (MVR_RASTER_EXACT_ONLY); the images are the same either way.
     `gather_backward`: skip the face-table backward kernel (MVR_BACKWARD_GATHER); same gradients up to summation order.
+    `normalize`: (mean, std) per channel (or scalars): the trainer's Normalize, (rgb - mean) / std, applied in the
+    rasteriser's stores (no pass over the frames afterwards); the backward differentiates the normalised images.
     `z_clip`: view depth of PyTorch3D >= 0.5's face clipping; None = the reference's rule (znear / 2 = 0.5 when
     perspective_correct — MeshRasterizer only clips for perspective cameras with it on —, else off); 0 = off."""
     if z_clip is None:
@@ -142,6 +144,14 @@ def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backface
         p.obj_color[k] = float(obj_color[k])
         p.bg_color[k] = float(bg_color[k])
     p.z_clip = float(z_clip)
+    if normalize is not None:
+        mean, std = normalize
+        mean = [float(mean)] * 3 if not hasattr(mean, "__len__") else [float(v) for v in mean]
+        std = [float(std)] * 3 if not hasattr(std, "__len__") else [float(v) for v in std]
+        if len(mean) != 3 or len(std) != 3 or min(std) <= 0:
+            raise ValueError("normalize: (mean, std) with three (or one) values each, std > 0")
+        for k in range(3):
+            p.out_mean[k], p.out_std[k] = mean[k], std[k]
     return p
 
 

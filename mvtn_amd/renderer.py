@@ -35,8 +35,13 @@ class MVRenderer(nn.Module):
     def __init__(self, nb_views, image_size=224, pc_rendering=True, object_color="white", background_color="white",
                  faces_per_pixel=1, points_radius=0.006, points_per_pixel=1, light_direction="random",
                  cull_backfaces=False, *, perspective_correct=True, rotation_check="device", strip_rows=0, z_clip=None,
-                 shader="hard_phong", blur_radius=0.0, sigma=1e-4, gamma=1e-4, return_alpha=False):
+                 shader="hard_phong", blur_radius=0.0, sigma=1e-4, gamma=1e-4, return_alpha=False, normalize=None):
         super().__init__()
+        # normalize=(mean, std): the trainer's Normalize (viewGCN/tools/Trainer_mvt.py:41-49) applied in the mesh rasteriser's
+        # stores — the images come out as (rgb - mean) / std, differentiably, with no pass over the frames afterwards
+        # (mvtn_amd.regularize.IMAGENET_MEAN / IMAGENET_STD are the reference's values).  Hard mesh path only.
+        self.normalize = None if normalize is None else (tuple(normalize[0]) if hasattr(normalize[0], "__len__") else (float(normalize[0]),) * 3,
+                                                          tuple(normalize[1]) if hasattr(normalize[1], "__len__") else (float(normalize[1]),) * 3)
         self.nb_views = nb_views
         self.image_size = image_size
         self.pc_rendering = pc_rendering
@@ -185,14 +190,15 @@ class MVRenderer(nn.Module):
                     self._light_cache[key] = light
         n_light = N if light is None else light.shape[0]
         pkey = (n_light, tuple(obj), tuple(float(c) for c in background_color), bool(self.cull_backfaces),
-                bool(self.perspective_correct), self.strip_rows, self.nb_views, self.image_size, self.z_clip)
+                bool(self.perspective_correct), self.strip_rows, self.nb_views, self.image_size, self.z_clip, self.normalize)
         params = self._params_cache.get(pkey)
         if params is None:
             if len(self._params_cache) > 64:
                 self._params_cache.clear()
             params = self._params_cache[pkey] = F.mesh_params(self.nb_views, self.image_size, n_light, pkey[1], pkey[2],
                                                               cull_backfaces=pkey[3], perspective_correct=pkey[4],
-                                                              strip_rows=self.strip_rows, z_clip=self.z_clip)
+                                                              strip_rows=self.strip_rows, z_clip=self.z_clip,
+                                                              normalize=self.normalize if self.shader == "hard_phong" else None)
         if azim.numel() != N:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (packed.n_meshes, self.nb_views))
         if self.shader != "hard_phong":

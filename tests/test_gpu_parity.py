@@ -298,6 +298,52 @@ def test_mesh_backward_through_cut_faces_against_finite_differences(oracle, dist
         assert rel < 2e-3, (name, rel, got, ref)
 
 
+@pytest.mark.parametrize("exact", [False, True])
+def test_normalize_fused_into_the_rasteriser_stores(exact):
+    """MVRenderer(normalize=(mean, std)) / mesh_params(normalize=...): the trainer's Normalize
+    (viewGCN/tools/Trainer_mvt.py:41-49) applied where the rasteriser stores its pixels — against the plain render followed
+    by torch's (x - mean) / std, images (background included) and gradients, through both rasterisers and, for the module,
+    the fused look-at node."""
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes, functional as F
+    from mvtn_amd.regularize import IMAGENET_MEAN, IMAGENET_STD
+    vl, fl = _mesh_batch([("M", 41), ("soup", 42), ("S", 43)])
+    B, V, size = 3, 4, 96
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    az, el, di = _views(B, 4, 44)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    mt, st = _t(np.array(mean)).view(1, 1, 3, 1, 1), _t(np.array(std)).view(1, 1, 3, 1, 1)
+    G = torch.randn(B, V, 3, size, size, generator=torch.Generator().manual_seed(45)).to(_dev())
+    out = {}
+    for fused in (False, True):
+        params = F.mesh_params(V, size, B * V, (0.9, 0.7, 0.5), (0.2, 0.4, 0.6), exact_raster=exact, normalize=(mean, std) if fused else None)
+        R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+        R, T = R.detach().requires_grad_(True), T.detach().requires_grad_(True)
+        light = F.camera_position_from_spherical_angles(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1))).detach().requires_grad_(True)
+        img = F.render_meshes(packed, R, T, light, params)
+        if not fused:
+            img = (img - mt) / st
+        img.backward(G)
+        out[fused] = (img.detach(), [x.grad.double() for x in (R, T, light)])
+    assert (out[True][0] - out[False][0]).abs().max() <= 2e-6 / min(std)
+    for a, b in zip(out[True][1], out[False][1]):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-9
+    if not exact:   # the module: one autograd node, ImageNet constants of the reference's trainer
+        r0 = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="relative").eval()
+        r1 = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="relative",
+                        normalize=(IMAGENET_MEAN, IMAGENET_STD)).eval()
+        res = []
+        for r in (r0, r1):
+            leaves = [_t(x).requires_grad_(True) for x in (az, el, di)]
+            img, _ = r(packed, None, *leaves)
+            if r is r0:
+                img = (img - IMAGENET_MEAN[0]) / IMAGENET_STD[0]
+            img.backward(G)
+            res.append((img.detach(), [t.grad.double() for t in leaves]))
+        assert (res[1][0] - res[0][0]).abs().max() <= 1e-5
+        for a, b in zip(res[1][1], res[0][1]):
+            assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-9
+
+
 def test_mesh_backward_at_the_c3_image_size_against_finite_differences(oracle):
     """C3's image size and mesh tier (224 px, 2 562 vertices / 5 120 faces: ~1 000 covered pixels and ~100 winning faces per
     8-row strip, the regime k_mesh_backward_tab is built for) against fp64 central differences of the oracle with the
