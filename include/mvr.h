@@ -108,6 +108,8 @@ typedef struct mvr_points_params {
                              -> PointsRenderer), the rasteriser uses float(r)^2 */
   float obj_color[3];
   float bg_color[3];
+  float out_mean[3];      /* as in mvr_mesh_params: the images come out as (rgb - out_mean) / out_std per channel */
+  float out_std[3];       /* (the trainer's Normalize in the rasteriser's stores); out_std[c] == 0: as rendered */
 } mvr_points_params;
 
 int mvr_version(void);

@@ -43,7 +43,8 @@ class PointsParams(ctypes.Structure):  # struct mvr_points_params
     _fields_ = [("n_clouds", ctypes.c_int32), ("n_points", ctypes.c_int32), ("n_views", ctypes.c_int32),
                 ("image_h", ctypes.c_int32), ("image_w", ctypes.c_int32), ("strip_rows", ctypes.c_int32),
                 ("points_per_pixel", ctypes.c_int32), ("reserved_", ctypes.c_int32),
-                ("radius", ctypes.c_double), ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3)]
+                ("radius", ctypes.c_double), ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3),
+                ("out_mean", ctypes.c_float * 3), ("out_std", ctypes.c_float * 3)]
 
 
 class PackLayout(ctypes.Structure):  # struct mvr_pack_layout

@@ -144,14 +144,7 @@ def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backface
         p.obj_color[k] = float(obj_color[k])
         p.bg_color[k] = float(bg_color[k])
     p.z_clip = float(z_clip)
-    if normalize is not None:
-        mean, std = normalize
-        mean = [float(mean)] * 3 if not hasattr(mean, "__len__") else [float(v) for v in mean]
-        std = [float(std)] * 3 if not hasattr(std, "__len__") else [float(v) for v in std]
-        if len(mean) != 3 or len(std) != 3 or min(std) <= 0:
-            raise ValueError("normalize: (mean, std) with three (or one) values each, std > 0")
-        for k in range(3):
-            p.out_mean[k], p.out_std[k] = mean[k], std[k]
+    _set_normalize(p, normalize)
     return p
 
 
@@ -424,12 +417,27 @@ def vertex_normals(packed: PackedMeshes):
 # point-cloud path
 # ---------------------------------------------------------------------------------------------
 
-def points_params(n_clouds, n_points, n_views, image_size, radius, obj_color, bg_color, strip_rows=0, points_per_pixel=1):
+def _set_normalize(p, normalize):
+    """(mean, std) per channel (or scalars) -> out_mean / out_std of a params struct: Normalize in the rasteriser's stores."""
+    if normalize is None:
+        return
+    mean, std = normalize
+    mean = [float(mean)] * 3 if not hasattr(mean, "__len__") else [float(v) for v in mean]
+    std = [float(std)] * 3 if not hasattr(std, "__len__") else [float(v) for v in std]
+    if len(mean) != 3 or len(std) != 3 or min(std) <= 0:
+        raise ValueError("normalize: (mean, std) with three (or one) values each, std > 0")
+    for k in range(3):
+        p.out_mean[k], p.out_std[k] = mean[k], std[k]
+
+
+def points_params(n_clouds, n_points, n_views, image_size, radius, obj_color, bg_color, strip_rows=0, points_per_pixel=1, normalize=None):
+    """`normalize`: (mean, std): the trainer's Normalize, (rgb - mean) / std, in the rasteriser's stores (see mesh_params)."""
     H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
     p = _lib.PointsParams(n_clouds, n_points, n_views, H, W, strip_rows, int(points_per_pixel), 0, radius)
     for k in range(3):
         p.obj_color[k] = float(obj_color[k])
         p.bg_color[k] = float(bg_color[k])
+    _set_normalize(p, normalize)
     return p
 
 

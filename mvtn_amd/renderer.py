@@ -39,7 +39,7 @@ class MVRenderer(nn.Module):
         super().__init__()
         # normalize=(mean, std): the trainer's Normalize (viewGCN/tools/Trainer_mvt.py:41-49) applied in the mesh rasteriser's
         # stores — the images come out as (rgb - mean) / std, differentiably, with no pass over the frames afterwards
-        # (mvtn_amd.regularize.IMAGENET_MEAN / IMAGENET_STD are the reference's values).  Hard mesh path only.
+        # (mvtn_amd.regularize.IMAGENET_MEAN / IMAGENET_STD are the reference's values).  Hard mesh path and point path.
         self.normalize = None if normalize is None else (tuple(normalize[0]) if hasattr(normalize[0], "__len__") else (float(normalize[0]),) * 3,
                                                           tuple(normalize[1]) if hasattr(normalize[1], "__len__") else (float(normalize[1]),) * 3)
         self.nb_views = nb_views
@@ -246,7 +246,7 @@ class MVRenderer(nn.Module):
             obj = [float(c) for c in color]
         params = F.points_params(B, P, self.nb_views, self.image_size, float(self.points_radius), obj,
                                  [float(c) for c in background_color], strip_rows=self.strip_rows,
-                                 points_per_pixel=int(self.points_per_pixel))
+                                 points_per_pixel=int(self.points_per_pixel), normalize=self.normalize)
         if azim.numel() != B * self.nb_views:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (B, self.nb_views))
         flat_dist = flatten_views(dist)

@@ -344,6 +344,38 @@ def test_normalize_fused_into_the_rasteriser_stores(exact):
             assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-9
 
 
+@pytest.mark.parametrize("K", [1, 3])
+def test_normalize_fused_into_the_point_rasteriser_stores(K):
+    """The same for the point path (K = 1: k_points_raster_shade, K = 3: the top-K kernel): MVRenderer(pc_rendering=True,
+    normalize=...) against the plain render followed by (x - mean) / std; images and the gradient w.r.t. the distance (the
+    only camera gradient of the point path that is not identically zero at K = 1 is in the clamp region; K = 3 has all)."""
+    from mvtn_amd import MVRenderer
+    B, P, V, size = 3, 1500, 4, 96
+    rng = np.random.default_rng(46)
+    pts = _t(rng.normal(size=(B, P, 3)) * 0.3)
+    cols = _t(rng.uniform(0, 1, (B, P, 3)))
+    az, el, _ = _views(B, 4, 47)
+    di = np.full((B, V), 1.0, np.float32)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    mt, st = _t(np.array(mean)).view(1, 1, 3, 1, 1), _t(np.array(std)).view(1, 1, 3, 1, 1)
+    G = torch.randn(B, V, 3, size, size, generator=torch.Generator().manual_seed(48)).to(_dev())
+    kw = dict(pc_rendering=True, object_color="custom", background_color="black", points_radius=0.02, points_per_pixel=K)
+    res = []
+    for fused in (False, True):
+        r = MVRenderer(V, size, normalize=(mean, std) if fused else None, **kw).eval()
+        leaves = [_t(x).requires_grad_(True) for x in (az, el, di)]
+        img, _ = r(None, pts, *leaves, color=cols)
+        if not fused:
+            img = (img - mt) / st
+        img.backward(G)
+        res.append((img.detach(), [t.grad.double() for t in leaves]))
+    assert (res[1][0] - res[0][0]).abs().max() <= 2e-6 / min(std)
+    for a, b in zip(res[1][1], res[0][1]):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-7
+    if K > 1:
+        assert all(g.abs().max() > 0 for g in res[0][1])
+
+
 def test_mesh_backward_at_the_c3_image_size_against_finite_differences(oracle):
     """C3's image size and mesh tier (224 px, 2 562 vertices / 5 120 faces: ~1 000 covered pixels and ~100 winning faces per
     8-row strip, the regime k_mesh_backward_tab is built for) against fp64 central differences of the oracle with the
