@@ -93,6 +93,15 @@ typedef struct mvr_mesh_params {
   float out_mean[3];      /* the trainer's Normalize (viewGCN/tools/Trainer_mvt.py:41-49) in the rasteriser's stores: the images */
   float out_std[3];       /* come out as (rgb - out_mean) / out_std per channel, the backward takes the gradient of THAT;
                              out_std[c] == 0 (a zeroed struct): channel c is stored as rendered.  Hard path only */
+  /* The reference's view regulariser (ops.py:138-176: view dropout, flip, replicate-pad, random crop) as a per-view SAMPLING
+   * WINDOW of the rasteriser: output pixel (row r, col c) of view n shows the source pixel (clamp(r + win_dy[n], 0, H-1),
+   * flip_n(clamp(c + win_dx[n], 0, W-1))) (flip_n(x) = W-1-x where win_flip[n] != 0), times win_scale[n] (before the Normalize
+   * above).  Device arrays of B*V entries; win_dx == NULL (a zeroed struct): none; win_scale may be NULL (= 1).  With
+   * crop offsets (i, j) and the padding of ops.py:143: win_dy = i - pad, win_dx = j - pad.  The frames, the pixel -> face
+   * map and the gradients are those of the windowed images.  Hard path only. */
+  const int32_t *win_dx, *win_dy;
+  const uint8_t *win_flip;
+  const float *win_scale;
 } mvr_mesh_params;
 
 typedef struct mvr_points_params {

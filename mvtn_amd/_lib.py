@@ -31,7 +31,8 @@ class MeshParams(ctypes.Structure):  # struct mvr_mesh_params
                 ("fov_deg", ctypes.c_float), ("ambient", ctypes.c_float), ("diffuse", ctypes.c_float),
                 ("specular", ctypes.c_float), ("shininess", ctypes.c_float),
                 ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3), ("z_clip", ctypes.c_float),
-                ("out_mean", ctypes.c_float * 3), ("out_std", ctypes.c_float * 3)]
+                ("out_mean", ctypes.c_float * 3), ("out_std", ctypes.c_float * 3),
+                ("win_dx", ctypes.c_void_p), ("win_dy", ctypes.c_void_p), ("win_flip", ctypes.c_void_p), ("win_scale", ctypes.c_void_p)]
 
 
 class SoftParams(ctypes.Structure):  # struct mvr_soft_params

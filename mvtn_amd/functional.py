@@ -148,6 +148,34 @@ def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backface
     return p
 
 
+def with_window(params, scale=None, flip=None, crop_i=None, crop_j=None, pad=0):
+    """A copy of `params` that makes the rasteriser render straight onto the reference's view-regulariser window
+    (ops.py:138-176): arguments as `mvtn_amd.regularize.draw_regularization` returns them — per image n = b*V + v a dropout
+    scale (f32) or None, a flip flag (u8) or None, crop offsets (i32) or None, and the padding.  The frames (and, through
+    the autograd nodes, their gradients) are those of render -> regualarize_rendered_views, with no pass over the frames."""
+    if scale is None and flip is None and crop_i is None:
+        return params
+    ref = next(t for t in (scale, flip, crop_i) if t is not None)
+    n, dev = ref.numel(), ref.device
+    zeros = torch.zeros(n, dtype=torch.int32, device=dev)
+    dx = zeros if crop_j is None else (crop_j.to(torch.int32) - int(pad)).contiguous()
+    dy = zeros if crop_i is None else (crop_i.to(torch.int32) - int(pad)).contiguous()
+    fl = torch.zeros(n, dtype=torch.uint8, device=dev) if flip is None else flip.to(torch.uint8).contiguous()
+    sc = None if scale is None else scale.to(torch.float32).contiguous()
+    _require_cuda(dx, dy, fl, sc)
+    p = _lib.MeshParams.from_buffer_copy(params)
+    p.win_dx, p.win_dy, p.win_flip, p.win_scale = dx.data_ptr(), dy.data_ptr(), fl.data_ptr(), (None if sc is None else sc.data_ptr())
+    p._keep = (dx, dy, fl, sc)   # the struct only holds their addresses
+    return p
+
+
+def _copy_params(params, extra_flags):
+    p = _lib.MeshParams.from_buffer_copy(params)
+    p.flags |= extra_flags
+    p._keep = getattr(params, "_keep", None)
+    return p
+
+
 class _RenderMeshes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, R, T, light, packed, params, need_grad):
@@ -161,8 +189,7 @@ class _RenderMeshes(torch.autograd.Function):
         dev = R.device
         mb = packed.c_struct()
         if need_grad:   # the rasteriser leaves its lists of covered pixels / winning faces for the backward
-            params = _lib.MeshParams.from_buffer_copy(params)
-            params.flags |= _lib.MVR_KEEP_PIXEL_LISTS
+            params = _copy_params(params, _lib.MVR_KEEP_PIXEL_LISTS)
         ws_bytes = lib.mvr_mesh_workspace_bytes(mb, params)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=dev)
@@ -183,8 +210,7 @@ class _RenderMeshes(torch.autograd.Function):
         N = R.shape[0]
         mb = packed.c_struct()
         ws_bytes = ws.numel()
-        bparams = _lib.MeshParams.from_buffer_copy(params)
-        bparams.flags |= _lib.MVR_WORKSPACE_FROM_FORWARD
+        bparams = _copy_params(params, _lib.MVR_WORKSPACE_FROM_FORWARD)
         gR, gT = torch.empty_like(R), torch.empty_like(T)
         per_view_light = params.n_light == N and N > 0 and ctx.needs_input_grad[2]
         gL = torch.empty(N, 3, dtype=torch.float32, device=R.device) if per_view_light else None
@@ -229,8 +255,7 @@ class _RenderMeshViews(torch.autograd.Function):
         sp = status.data_ptr() if host_status is None else host_status.data_ptr()
         mb = packed.c_struct()
         if need_grad:   # the rasteriser leaves its lists of covered pixels / winning faces for the backward
-            params = _lib.MeshParams.from_buffer_copy(params)
-            params.flags |= _lib.MVR_KEEP_PIXEL_LISTS
+            params = _copy_params(params, _lib.MVR_KEEP_PIXEL_LISTS)
         ws_bytes = packed.workspace_bytes(params)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         images = torch.empty(B, V, 3, H, W, dtype=torch.float32, device=dev)
@@ -256,8 +281,7 @@ class _RenderMeshViews(torch.autograd.Function):
         dev = R.device
         aux_p = aux.data_ptr()
         light_p = aux_p + 8 * N if ctx.relative else light.data_ptr()
-        bparams = _lib.MeshParams.from_buffer_copy(params)
-        bparams.flags |= _lib.MVR_WORKSPACE_FROM_FORWARD
+        bparams = _copy_params(params, _lib.MVR_WORKSPACE_FROM_FORWARD)
         grads = torch.empty(3, N, dtype=torch.float32, device=dev)
         gp = grads.data_ptr()
         if g is not None and gR_ext is None and gT_ext is None:   # the training step: everything in one call
@@ -368,8 +392,7 @@ class _RenderMeshesSoft(torch.autograd.Function):
         packed, params, soft = ctx.packed, ctx.params, ctx.soft
         g = _f32c(g)
         N = R.shape[0]
-        bparams = _lib.MeshParams.from_buffer_copy(params)
-        bparams.flags |= _lib.MVR_WORKSPACE_FROM_FORWARD
+        bparams = _copy_params(params, _lib.MVR_WORKSPACE_FROM_FORWARD)
         gR, gT = torch.empty_like(R), torch.empty_like(T)
         per_view_light = params.n_light == N and N > 0 and ctx.needs_input_grad[2]
         gL = torch.empty(N, 3, dtype=torch.float32, device=R.device) if per_view_light else None

@@ -162,7 +162,7 @@ class MVRenderer(nn.Module):
                 sys.exit("Remedy did not work")
 
     # -- models/renderer.py:65-114 ---------------------------------------------------------------
-    def render_meshes(self, meshes, color, azim, elev, dist, lights, background_color=(1.0, 1.0, 1.0)):
+    def render_meshes(self, meshes, color, azim, elev, dist, lights, background_color=(1.0, 1.0, 1.0), window=None):
         device = azim.device
         vert_colors = None
         if torch.is_tensor(color) and color.dim() >= 2:  # "custom": per-vertex colours (B, >=Vn, 3)
@@ -201,6 +201,10 @@ class MVRenderer(nn.Module):
                                                               normalize=self.normalize if self.shader == "hard_phong" else None)
         if azim.numel() != N:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (packed.n_meshes, self.nb_views))
+        if window is not None:   # render straight onto the view regulariser's window (regularize.draw_regularization)
+            if self.shader != "hard_phong":
+                raise ValueError("window: hard mesh path only")
+            params = F.with_window(params, *window)
         if self.shader != "hard_phong":
             return self._render_meshes_soft(packed, azim, elev, dist, light, params)
         # look-at (+ remedy) -> light -> rasterise + shade as ONE autograd node
@@ -269,10 +273,13 @@ class MVRenderer(nn.Module):
         return images, Cameras(R, T, "orthographic", znear=0.01)
 
     # -- models/renderer.py:173-198 ------------------------------------------------------------------
-    def forward(self, meshes, points, azim, elev, dist, color=None):
+    def forward(self, meshes, points, azim, elev, dist, color=None, window=None):
         """meshes: list of B single-mesh objects with verts_list()/faces_list() (or one batched
         object, or a PackedMeshes already resident on the GPU), or None; points: (B,P,3) or None;
         azim/elev/dist: (B, nb_views) float tensors on the GPU, degrees.
+        `window` (keyword, mesh path): the draws of one `regualarize_rendered_views` call as
+        `mvtn_amd.regularize.draw_regularization` returns them (scale, flip, crop_i, crop_j, pad): the views are rendered
+        straight onto the dropped / flipped / padded / cropped frames (no pass over them afterwards), differentiably.
         Returns (rendered_images (B, nb_views, 3, H, W) float32, cameras)."""
         if not azim.is_cuda:
             raise RuntimeError("MVRenderer: azim/elev/dist must be CUDA tensors (models/renderer.py hard-codes .cuda() too)")
@@ -289,7 +296,9 @@ class MVRenderer(nn.Module):
             relative = not (self.light_direction_type == "fixed" or (self.light_direction_type == "random" and self.training))
             lights = None if relative else self.light_direction(azim, elev, dist)
             return self.render_meshes(meshes=meshes, color=color, azim=azim, elev=elev, dist=dist, lights=lights,
-                                      background_color=background_color)
+                                      background_color=background_color, window=window)
+        if window is not None:
+            raise ValueError("window: mesh path only")
         return self.render_points(points=points, color=color, azim=azim, elev=elev, dist=dist,
                                   background_color=background_color)
 

@@ -344,6 +344,75 @@ def test_normalize_fused_into_the_rasteriser_stores(exact):
             assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-9
 
 
+@pytest.mark.parametrize("exact", [False, True])
+def test_regulariser_window_rendered_by_the_rasteriser(exact):
+    """MVRenderer(...)(..., window=draws) / functional.with_window: the reference's view regulariser (ops.py:138-176: view
+    dropout, flip, replicate-pad 67, random 224-crop) as the rasteriser's grid of sample positions — against the plain render
+    followed by `apply_regularization` with the same draws (itself bit-exact to the reference's composition): identical
+    frames from the exact kernel (the same arithmetic at the same sample positions; an ulp apart from the fast kernel, in the
+    strips it hands to the exact one), identical pixel -> face maps, gradients to round-off; with
+    the Normalize in the stores on top; through both rasterisers; objects reaching the image border (close camera), so that
+    the replicated edge rows / columns are not all background."""
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes, functional as F, regularize as rg
+    vl, fl = _mesh_batch([("M", 51), ("S", 52), ("soup", 53)])
+    B, V, size = 3, 4, 96
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    az, el, _ = _views(B, 4, 54)
+    di = np.full((B, V), 1.6, np.float32)   # fills the frame: the border pixels are covered in several views
+    torch.manual_seed(55)
+    draws = rg.draw_regularization(B, V, size, _dev(), dropout_p=0.3, augment_training=True, crop_ratio=0.3)
+    scale, flip, ci, cj, pad = draws
+    assert pad == int(1.3 * size) - size and int(flip.sum()) not in (0, B * V) and float(scale.min()) == 0.0
+    G = torch.randn(B, V, 3, size, size, generator=torch.Generator().manual_seed(56)).to(_dev())
+    obj, bg = (0.9, 0.7, 0.5), (0.2, 0.4, 0.6)
+    light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
+    res = {}
+    for fused in (False, True):
+        params = F.mesh_params(V, size, 1, obj, bg, exact_raster=exact)
+        if fused:
+            params = F.with_window(params, *draws)
+        R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+        R, T = R.detach().requires_grad_(True), T.detach().requires_grad_(True)
+        img = F.render_meshes(packed, R, T, light, params)
+        if not fused:
+            img = rg.apply_regularization(img, *draws)
+        img.backward(G)
+        _, p2f = F.render_meshes_fragments(packed, R.detach(), T.detach(), light, params)
+        res[fused] = (img.detach(), p2f, R.grad.double(), T.grad.double())
+    if exact:
+        assert torch.equal(res[True][0], res[False][0])
+    else:
+        # the fast rasteriser hands undecidable strips (the soup's coincident faces) to the exact kernel, whose shading rounds
+        # differently (test_fast_rasteriser_equals_exact_kernel); WHICH output strips those are moves with the window
+        assert (res[True][0] - res[False][0]).abs().max() <= 5e-7
+    # the windowed pixel -> face map is the plain one seen through the window
+    n_idx = torch.arange(B * V, device=_dev()).view(-1, 1, 1)
+    rows = (torch.arange(size, device=_dev()).view(1, -1, 1) + (ci.view(-1, 1, 1) - pad)).clamp(0, size - 1)
+    cols = (torch.arange(size, device=_dev()).view(1, 1, -1) + (cj.view(-1, 1, 1) - pad)).clamp(0, size - 1)
+    cols = torch.where(flip.view(-1, 1, 1) != 0, size - 1 - cols, cols)
+    assert torch.equal(res[True][1], res[False][1][n_idx, rows, cols])
+    border = res[False][1][:, [0, -1], :]
+    assert int((border >= 0).sum()) > 0, "the test wants covered border pixels"
+    for a, b in ((res[True][2], res[False][2]), (res[True][3], res[False][3])):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-9
+    if not exact:   # the module, with dropout + augmentation + Normalize in one render
+        r0 = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="relative").train()
+        r1 = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="relative",
+                        normalize=(rg.IMAGENET_MEAN, rg.IMAGENET_STD)).train()
+        out = []
+        for r in (r0, r1):
+            leaves = [_t(x).requires_grad_(True) for x in (az, el, di)]
+            if r is r0:
+                img = rg.apply_regularization(r(packed, None, *leaves)[0], *draws, mean=rg.IMAGENET_MEAN, std=rg.IMAGENET_STD)
+            else:
+                img = r(packed, None, *leaves, window=draws)[0]
+            img.backward(G)
+            out.append((img.detach(), [t.grad.double() for t in leaves]))
+        assert (out[1][0] - out[0][0]).abs().max() <= 1e-5
+        for a, b in zip(out[1][1], out[0][1]):
+            assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-9
+
+
 @pytest.mark.parametrize("K", [1, 3])
 def test_normalize_fused_into_the_point_rasteriser_stores(K):
     """The same for the point path (K = 1: k_points_raster_shade, K = 3: the top-K kernel): MVRenderer(pc_rendering=True,
