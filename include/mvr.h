@@ -119,6 +119,11 @@ typedef struct mvr_points_params {
   float bg_color[3];
   float out_mean[3];      /* as in mvr_mesh_params: the images come out as (rgb - out_mean) / out_std per channel */
   float out_std[3];       /* (the trainer's Normalize in the rasteriser's stores); out_std[c] == 0: as rendered */
+  /* per-view sampling window, exactly as in `mvr_mesh_params`: the view regulariser of ops.py:138-176 rendered by the point
+   * rasterisers, K = 1 and K > 1, forward and backward; device arrays of B*V entries; win_dx == NULL: none */
+  const int32_t *win_dx, *win_dy;
+  const uint8_t *win_flip;
+  const float *win_scale;
 } mvr_points_params;
 
 int mvr_version(void);

@@ -45,7 +45,8 @@ class PointsParams(ctypes.Structure):  # struct mvr_points_params
                 ("image_h", ctypes.c_int32), ("image_w", ctypes.c_int32), ("strip_rows", ctypes.c_int32),
                 ("points_per_pixel", ctypes.c_int32), ("reserved_", ctypes.c_int32),
                 ("radius", ctypes.c_double), ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3),
-                ("out_mean", ctypes.c_float * 3), ("out_std", ctypes.c_float * 3)]
+                ("out_mean", ctypes.c_float * 3), ("out_std", ctypes.c_float * 3),
+                ("win_dx", ctypes.c_void_p), ("win_dy", ctypes.c_void_p), ("win_flip", ctypes.c_void_p), ("win_scale", ctypes.c_void_p)]
 
 
 class PackLayout(ctypes.Structure):  # struct mvr_pack_layout

@@ -149,7 +149,7 @@ def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backface
 
 
 def with_window(params, scale=None, flip=None, crop_i=None, crop_j=None, pad=0):
-    """A copy of `params` that makes the rasteriser render straight onto the reference's view-regulariser window
+    """A copy of `params` (mesh_params or points_params) that makes the rasteriser render straight onto the reference's view-regulariser window
     (ops.py:138-176): arguments as `mvtn_amd.regularize.draw_regularization` returns them — per image n = b*V + v a dropout
     scale (f32) or None, a flip flag (u8) or None, crop offsets (i32) or None, and the padding.  The frames (and, through
     the autograd nodes, their gradients) are those of render -> regualarize_rendered_views, with no pass over the frames."""
@@ -163,7 +163,7 @@ def with_window(params, scale=None, flip=None, crop_i=None, crop_j=None, pad=0):
     fl = torch.zeros(n, dtype=torch.uint8, device=dev) if flip is None else flip.to(torch.uint8).contiguous()
     sc = None if scale is None else scale.to(torch.float32).contiguous()
     _require_cuda(dx, dy, fl, sc)
-    p = _lib.MeshParams.from_buffer_copy(params)
+    p = type(params).from_buffer_copy(params)   # (MeshParams or PointsParams: the same four fields)
     p.win_dx, p.win_dy, p.win_flip, p.win_scale = dx.data_ptr(), dy.data_ptr(), fl.data_ptr(), (None if sc is None else sc.data_ptr())
     p._keep = (dx, dy, fl, sc)   # the struct only holds their addresses
     return p

@@ -239,7 +239,7 @@ class MVRenderer(nn.Module):
         return (rgba if self.return_alpha else rgba[:, :, 0:3]), Cameras(R, T, "perspective")
 
     # -- models/renderer.py:116-151 ----------------------------------------------------------------
-    def render_points(self, points, color, azim, elev, dist, background_color=(0.0, 0.0, 0.0)):
+    def render_points(self, points, color, azim, elev, dist, background_color=(0.0, 0.0, 0.0), window=None):
         device = azim.device
         B, P = points.shape[0], points.shape[1]
         pts = points.to(device=device, dtype=torch.float32, non_blocking=True).contiguous()
@@ -251,6 +251,8 @@ class MVRenderer(nn.Module):
         params = F.points_params(B, P, self.nb_views, self.image_size, float(self.points_radius), obj,
                                  [float(c) for c in background_color], strip_rows=self.strip_rows,
                                  points_per_pixel=int(self.points_per_pixel), normalize=self.normalize)
+        if window is not None:   # render straight onto the view regulariser's window (regularize.draw_regularization)
+            params = F.with_window(params, *window)
         if azim.numel() != B * self.nb_views:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (B, self.nb_views))
         flat_dist = flatten_views(dist)
@@ -277,7 +279,7 @@ class MVRenderer(nn.Module):
         """meshes: list of B single-mesh objects with verts_list()/faces_list() (or one batched
         object, or a PackedMeshes already resident on the GPU), or None; points: (B,P,3) or None;
         azim/elev/dist: (B, nb_views) float tensors on the GPU, degrees.
-        `window` (keyword, mesh path): the draws of one `regualarize_rendered_views` call as
+        `window` (keyword; hard mesh path and point path): the draws of one `regualarize_rendered_views` call as
         `mvtn_amd.regularize.draw_regularization` returns them (scale, flip, crop_i, crop_j, pad): the views are rendered
         straight onto the dropped / flipped / padded / cropped frames (no pass over them afterwards), differentiably.
         Returns (rendered_images (B, nb_views, 3, H, W) float32, cameras)."""
@@ -297,10 +299,8 @@ class MVRenderer(nn.Module):
             lights = None if relative else self.light_direction(azim, elev, dist)
             return self.render_meshes(meshes=meshes, color=color, azim=azim, elev=elev, dist=dist, lights=lights,
                                       background_color=background_color, window=window)
-        if window is not None:
-            raise ValueError("window: mesh path only")
         return self.render_points(points=points, color=color, azim=azim, elev=elev, dist=dist,
-                                  background_color=background_color)
+                                  background_color=background_color, window=window)
 
     # -- models/renderer.py:200-207 -------------------------------------------------------------------
     def render_and_save(self, meshes, points, azim, elev, dist, images_path, cameras_path, color=None):

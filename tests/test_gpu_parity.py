@@ -445,6 +445,68 @@ def test_normalize_fused_into_the_point_rasteriser_stores(K):
         assert all(g.abs().max() > 0 for g in res[0][1])
 
 
+@pytest.mark.parametrize("K", [1, 3])
+def test_regulariser_window_rendered_by_the_point_rasterisers(K):
+    """The point path's version of test_regulariser_window_rendered_by_the_rasteriser (K = 1: k_points_raster_shade_win,
+    K = 3: k_points_raster_topk_win): MVRenderer(pc_rendering=True)(..., window=draws) against the plain render followed by
+    `apply_regularization` with the same draws — identical frames (same arithmetic at the same sample positions), the
+    pixel -> point map seen through the window, gradients to round-off; a close camera, so that discs reach the border and
+    the replicated rows / columns are not all background; with the Normalize in the stores on top."""
+    from mvtn_amd import MVRenderer, functional as F, regularize as rg
+    B, P, V, size = 3, 1500, 4, 96
+    rng = np.random.default_rng(61)
+    pts = _t(rng.normal(size=(B, P, 3)) * 0.45)
+    cols = _t(rng.uniform(0, 1, (B, P, 3)))
+    az, el, _ = _views(B, 4, 62)
+    di = np.full((B, V), 1.0, np.float32)
+    torch.manual_seed(63)
+    draws = rg.draw_regularization(B, V, size, _dev(), dropout_p=0.3, augment_training=True, crop_ratio=0.3)
+    scale, flip, ci, cj, pad = draws
+    assert int(flip.sum()) not in (0, B * V) and float(scale.min()) == 0.0
+    G = torch.randn(B, V, 3, size, size, generator=torch.Generator().manual_seed(64)).to(_dev())
+    # the library calls: frames and pixel -> point maps
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    res = {}
+    for fused in (False, True):
+        params = F.points_params(B, P, V, size, 0.02, (1.0, 1.0, 1.0), (0.1, 0.2, 0.3), points_per_pixel=K)
+        if fused:
+            params = F.with_window(params, *draws)
+        Rg, Tg, dg = R.detach().clone().requires_grad_(True), T.detach().clone().requires_grad_(True), _t(di.reshape(-1)).requires_grad_(True)
+        img = F.render_points(pts, cols, Rg, Tg, dg, params)
+        p2p = img.grad_fn.saved_tensors[4].clone()
+        if not fused:
+            img = rg.apply_regularization(img, *draws)
+        img.backward(G)
+        res[fused] = (img.detach(), p2p, [x.grad.double() for x in (Rg, Tg, dg)])
+    assert torch.equal(res[True][0], res[False][0])
+    n_idx = torch.arange(B * V, device=_dev()).view(-1, 1, 1)
+    rows = (torch.arange(size, device=_dev()).view(1, -1, 1) + (ci.view(-1, 1, 1) - pad)).clamp(0, size - 1)
+    cols_i = (torch.arange(size, device=_dev()).view(1, 1, -1) + (cj.view(-1, 1, 1) - pad)).clamp(0, size - 1)
+    cols_i = torch.where(flip.view(-1, 1, 1) != 0, size - 1 - cols_i, cols_i)
+    assert torch.equal(res[True][1], res[False][1][n_idx, rows, cols_i])
+    plain_map = res[False][1] if K == 1 else res[False][1][..., 0]
+    assert int((plain_map[:, [0, -1], :] >= 0).sum()) > 0 and int((plain_map[:, :, [0, -1]] >= 0).sum()) > 0, "the test wants covered border pixels"
+    for a, b in zip(res[True][2], res[False][2]):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-7
+    if K > 1:
+        assert all(g.abs().max() > 0 for g in res[False][2])
+    # the module, with the Normalize in the stores
+    kw = dict(pc_rendering=True, object_color="custom", background_color="black", points_radius=0.02, points_per_pixel=K)
+    out = []
+    for fused in (False, True):
+        r = MVRenderer(V, size, normalize=(rg.IMAGENET_MEAN, rg.IMAGENET_STD) if fused else None, **kw).train()
+        leaves = [_t(x).requires_grad_(True) for x in (az, el, di)]
+        if fused:
+            img = r(None, pts, *leaves, color=cols, window=draws)[0]
+        else:
+            img = rg.apply_regularization(r(None, pts, *leaves, color=cols)[0], *draws, mean=rg.IMAGENET_MEAN, std=rg.IMAGENET_STD)
+        img.backward(G)
+        out.append((img.detach(), [t.grad.double() for t in leaves]))
+    assert (out[1][0] - out[0][0]).abs().max() <= 1e-5
+    for a, b in zip(out[1][1], out[0][1]):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-7
+
+
 def test_mesh_backward_at_the_c3_image_size_against_finite_differences(oracle):
     """C3's image size and mesh tier (224 px, 2 562 vertices / 5 120 faces: ~1 000 covered pixels and ~100 winning faces per
     8-row strip, the regime k_mesh_backward_tab is built for) against fp64 central differences of the oracle with the
