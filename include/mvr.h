@@ -102,6 +102,8 @@ typedef struct mvr_mesh_params {
   const int32_t *win_dx, *win_dy;
   const uint8_t *win_flip;
   const float *win_scale;
+  int32_t win_pad;        /* subtracted from every win_dx / win_dy entry: the arrays may then hold the crop offsets (j, i) as drawn */
+  int32_t reserved2_;     /* explicit padding; must be 0 */
 } mvr_mesh_params;
 
 typedef struct mvr_points_params {
@@ -124,6 +126,8 @@ typedef struct mvr_points_params {
   const int32_t *win_dx, *win_dy;
   const uint8_t *win_flip;
   const float *win_scale;
+  int32_t win_pad;        /* as in mvr_mesh_params */
+  int32_t reserved2_;     /* explicit padding; must be 0 */
 } mvr_points_params;
 
 int mvr_version(void);

@@ -32,7 +32,8 @@ class MeshParams(ctypes.Structure):  # struct mvr_mesh_params
                 ("specular", ctypes.c_float), ("shininess", ctypes.c_float),
                 ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3), ("z_clip", ctypes.c_float),
                 ("out_mean", ctypes.c_float * 3), ("out_std", ctypes.c_float * 3),
-                ("win_dx", ctypes.c_void_p), ("win_dy", ctypes.c_void_p), ("win_flip", ctypes.c_void_p), ("win_scale", ctypes.c_void_p)]
+                ("win_dx", ctypes.c_void_p), ("win_dy", ctypes.c_void_p), ("win_flip", ctypes.c_void_p), ("win_scale", ctypes.c_void_p),
+                ("win_pad", ctypes.c_int32), ("reserved2_", ctypes.c_int32)]
 
 
 class SoftParams(ctypes.Structure):  # struct mvr_soft_params
@@ -46,7 +47,8 @@ class PointsParams(ctypes.Structure):  # struct mvr_points_params
                 ("points_per_pixel", ctypes.c_int32), ("reserved_", ctypes.c_int32),
                 ("radius", ctypes.c_double), ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3),
                 ("out_mean", ctypes.c_float * 3), ("out_std", ctypes.c_float * 3),
-                ("win_dx", ctypes.c_void_p), ("win_dy", ctypes.c_void_p), ("win_flip", ctypes.c_void_p), ("win_scale", ctypes.c_void_p)]
+                ("win_dx", ctypes.c_void_p), ("win_dy", ctypes.c_void_p), ("win_flip", ctypes.c_void_p), ("win_scale", ctypes.c_void_p),
+                ("win_pad", ctypes.c_int32), ("reserved2_", ctypes.c_int32)]
 
 
 class PackLayout(ctypes.Structure):  # struct mvr_pack_layout

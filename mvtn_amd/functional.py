@@ -157,14 +157,23 @@ def with_window(params, scale=None, flip=None, crop_i=None, crop_j=None, pad=0):
         return params
     ref = next(t for t in (scale, flip, crop_i) if t is not None)
     n, dev = ref.numel(), ref.device
-    zeros = torch.zeros(n, dtype=torch.int32, device=dev)
-    dx = zeros if crop_j is None else (crop_j.to(torch.int32) - int(pad)).contiguous()
-    dy = zeros if crop_i is None else (crop_i.to(torch.int32) - int(pad)).contiguous()
-    fl = torch.zeros(n, dtype=torch.uint8, device=dev) if flip is None else flip.to(torch.uint8).contiguous()
-    sc = None if scale is None else scale.to(torch.float32).contiguous()
+
+    def as_is(t, dtype):   # no kernel when the draws already have the library's types (draw_regularization's do)
+        return t if t.dtype == dtype and t.is_contiguous() else t.to(dtype).contiguous()
+    if crop_i is not None and crop_j is not None:
+        # the crop offsets go in as drawn: the library subtracts `win_pad` itself (no elementwise launch per step)
+        dx, dy, win_pad = as_is(crop_j, torch.int32), as_is(crop_i, torch.int32), int(pad)
+    else:
+        zeros = torch.zeros(n, dtype=torch.int32, device=dev)
+        dx = zeros if crop_j is None else (crop_j.to(torch.int32) - int(pad)).contiguous()
+        dy = zeros if crop_i is None else (crop_i.to(torch.int32) - int(pad)).contiguous()
+        win_pad = 0
+    fl = torch.zeros(n, dtype=torch.uint8, device=dev) if flip is None else as_is(flip, torch.uint8)
+    sc = None if scale is None else as_is(scale, torch.float32)
     _require_cuda(dx, dy, fl, sc)
-    p = type(params).from_buffer_copy(params)   # (MeshParams or PointsParams: the same four fields)
+    p = type(params).from_buffer_copy(params)   # (MeshParams or PointsParams: the same fields)
     p.win_dx, p.win_dy, p.win_flip, p.win_scale = dx.data_ptr(), dy.data_ptr(), fl.data_ptr(), (None if sc is None else sc.data_ptr())
+    p.win_pad = win_pad
     p._keep = (dx, dy, fl, sc)   # the struct only holds their addresses
     return p
 

@@ -110,8 +110,8 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.mvr_version() >= 100
     # struct layouts agree with the header (sizes computed by hand from include/mvr.h)
     assert ctypes.sizeof(_lib.MeshBatch) == 6 * 4 + 5 * 8
-    assert ctypes.sizeof(_lib.MeshParams) == 6 * 4 + 5 * 4 + 6 * 4 + 4 + 6 * 4 + 4 * 8
-    assert ctypes.sizeof(_lib.PointsParams) == 8 * 4 + 8 + 6 * 4 + 6 * 4 + 4 * 8
+    assert ctypes.sizeof(_lib.MeshParams) == 6 * 4 + 5 * 4 + 6 * 4 + 4 + 6 * 4 + 4 * 8 + 8
+    assert ctypes.sizeof(_lib.PointsParams) == 8 * 4 + 8 + 6 * 4 + 6 * 4 + 4 * 8 + 8
 
 
 def test_c_abi_argument_validation_without_gpu():
