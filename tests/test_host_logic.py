@@ -162,6 +162,17 @@ def test_flag_constants_and_workspace_rules_without_gpu():
     assert b"z_clip" in lib.mvr_last_error()
     assert F.mesh_params(12, 224, 1, (1, 1, 1), (1, 1, 1), perspective_correct=False).z_clip == 0.0   # the default follows the reference's rule
     assert abs(F.mesh_params(12, 224, 1, (1, 1, 1), (1, 1, 1)).z_clip - 0.5) < 1e-12
+    # the sampling-window fields go together (mesh and point parameters), also checked before any HIP call
+    for make, call in ((lambda: F.mesh_params(12, 224, 1, (1, 1, 1), (1, 1, 1)),
+                        lambda p: lib.mvr_render_meshes_forward(mb, p, 1, 1, 1, 1, None, 1, 1 << 40, None)),
+                       (lambda: F.points_params(2, 100, 12, 224, 0.006, (1, 1, 1), (0, 0, 0)),
+                        lambda p: lib.mvr_render_points_forward(p, 1, None, 1, 1, 1, 1, None, 1, 1 << 40, None))):
+        for fields in ({"win_dx": 1}, {"win_dx": 1, "win_dy": 1}, {"win_scale": 1}, {"win_pad": 3}, {"reserved2_": 1}):
+            p = make()
+            for k, v in fields.items():
+                setattr(p, k, v)
+            assert call(p) == 1, fields
+            assert b"win_" in lib.mvr_last_error() or b"reserved2_" in lib.mvr_last_error(), (fields, lib.mvr_last_error())
 
 
 def test_product_has_no_cpu_fallback_and_never_imports_the_oracle():
