@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """bench.py — rendered views/s of the MVRenderer hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mesh_fwd|mesh_fwdbwd|points_fwd|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mesh_fwd|mesh_fwdbwd|points_fwd|c5|c5_per_gpu|soft_fwdbwd]
 
 `--gpus N` with N > 1 and no RANK in the environment starts its own N ranks (torch.distributed.run on 127.0.0.1, one
 per GPU) BEFORE anything touches a GPU, relays rank 0's JSON line and exits with the children's status; started by a
 launcher (RANK set) it is one of the ranks.  On a box with fewer than N visible GPUs it fails loudly.
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
-MVRenderer.forward (look-at + validity/remedy + vertex normals + projection + rasterise + shade) on
-B=16 "ModelNet-simplified-sized" meshes x 12 spherical views at 224x224 (BASELINE.json configs[1]).
-For N>1 the driver launches one rank per GPU with torch.distributed.run; every rank renders its own
-B objects (the (B x V) view axis shards by object: weak scaling, no data-path collective); the
-RCCL all-gather of the rendered views the north_star names is timed separately and reported beside it.
+MVRenderer.forward (look-at + validity/remedy + vertex normals + projection + rasterise + shade).
+Default workload at N = 1: B=16 "ModelNet-simplified-sized" meshes x 12 spherical views at 224x224 (BASELINE.json
+configs[1], the configuration the metric is quoted on).  Default at N > 1: BASELINE.json configs[4] — 64 ShapeNet-sized
+(tier L) meshes x 20 views IN TOTAL, sharded by object over the N ranks (64/N objects per GPU: fixed total work,
+"scaling": "strong"), every step = render the local shard + the RCCL all-gather of the rendered views the north_star
+names, so `value` INCLUDES the gather; the gather-free rate and the exchange hidden behind the rendering are reported
+beside it (`allgather`).  Any other workload at N > 1 gives every rank its own B objects (weak scaling, no data-path
+collective, the gather timed beside it).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      algorithmic HBM bytes per launch of the dominant kernel / its HIP-event duration
@@ -42,8 +45,12 @@ def parse():
     # final synchronisation) is amortised — 100 steps read 5 % low (120.4 vs 114.3 us per C2 step); still < 1 s of GPU time
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="mesh_fwd", choices=["mesh_fwd", "mesh_fwdbwd", "points_fwd", "c5"],
-                    help="c5 = BASELINE configs[4] per GPU: 8 ShapeNet-sized (tier L) meshes x 20 views, mesh render fwd")
+    ap.add_argument("--workload", default=None, choices=["mesh_fwd", "mesh_fwdbwd", "points_fwd", "c5", "c5_per_gpu", "soft_fwdbwd"],
+                    help="default: mesh_fwd (C2) on one GPU, c5 on several.  c5 = BASELINE configs[4]: 64 ShapeNet-sized (tier L) "
+                         "meshes x 20 views in total, sharded over the GPUs, the all-gather inside the step; c5_per_gpu = 8 such "
+                         "meshes per GPU (one GPU's share at N = 8; weak scaling); soft_fwdbwd = C3's shape through the "
+                         "SoftPhongShader path (K = 4, sigma = 1e-4)")
+    ap.add_argument("--forward-pieces", type=int, default=0, help="mvr_set_forward_pieces for the timed steps (0 = automatic)")
     ap.add_argument("--batch", type=int, default=0, help="objects per GPU (default: the BASELINE config's)")
     ap.add_argument("--views", type=int, default=0)
     ap.add_argument("--image-size", type=int, default=224)
@@ -53,8 +60,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-stream throughput leg")
-    ap.add_argument("--exchange-pieces", type=int, default=0,
-                    help="N>1: also time mvtn_amd.distributed.render_sharded_overlapped with this many pieces (0 = off)")
+    ap.add_argument("--exchange-pieces", type=int, default=-1,
+                    help="N>1: also time mvtn_amd.distributed.render_sharded_overlapped with this many pieces (0 = off; default: 2 for c5, else off)")
     ap.add_argument("--host-meshes", action="store_true", help="hand CPU meshes to every step (the reference's interface): packing + H2D inside the timed region; documentation only, never the headline")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (self-test of the N>1 code path)")
     ap.add_argument("--cpu-views", type=int, default=16, help="views in the cpu_baseline sample (~0.7 s each for meshes)")
@@ -141,8 +148,26 @@ def self_launch(args):
     sys.exit(0)
 
 
+def timed(step, steps, barrier, dist_on, dev):
+    """K steps bracketed by barrier + synchronize on both sides; MAX over ranks.  Returns seconds."""
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
 def main():
     args = parse()
+    if args.workload is None:
+        args.workload = "c5" if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 else "mesh_fwd"
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
     # Only the JSON line may reach stdout: libraries (RCCL prints a version banner on fd 1) are diverted to stderr
@@ -164,18 +189,33 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, synthetic as syn
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, functional as F, synthetic as syn
+    from mvtn_amd.distributed import shard_range
     lib = _lib.load()
 
-    c5 = args.workload == "c5"
-    if c5:   # BASELINE configs[4]: B=64 tier-L meshes x 20 views over 8 GPUs = 8 objects per GPU (weak scaling from there)
+    wl_name = args.workload
+    c5 = wl_name in ("c5", "c5_per_gpu")
+    soft = wl_name == "soft_fwdbwd"
+    fixed_total = wl_name == "c5" and not args.batch      # BASELINE configs[4]: 64 objects IN TOTAL, sharded over the ranks
+    seed0 = 0                                              # first object's seed on this rank
+    if c5:
         args.workload, args.tier = "mesh_fwd", "L"
-        args.batch, args.views = args.batch or 8, args.views or 20
+        args.views = args.views or 20
+        if fixed_total:
+            lo, hi = shard_range(64, world, rank)
+            args.batch, seed0 = hi - lo, lo
+        else:
+            args.batch = args.batch or 8
+    if soft:
+        args.workload = "mesh_fwdbwd"
     H = W = args.image_size
     if args.workload == "points_fwd":
         B, V, P = args.batch or 20, args.views or 20, 2048
     else:
         B, V, P = args.batch or 16, args.views or 12, 0
+    if not fixed_total:
+        seed0 = rank * B
+    n_views_total = 64 * V if fixed_total else B * V * world
     az, el, di = syn.spherical_views(V)
     if args.workload == "points_fwd":
         di = np.full(V, 1.0, np.float32)
@@ -187,15 +227,15 @@ def main():
     if args.workload == "points_fwd":
         clouds = []
         for i in range(B):
-            v, f = syn.synthetic_mesh(args.tier, rank * B + i)
-            clouds.append(syn.surface_points(v, f, P, seed=rank * B + i))
+            v, f = syn.synthetic_mesh(args.tier, seed0 + i)
+            clouds.append(syn.surface_points(v, f, P, seed=seed0 + i))
         points = torch.from_numpy(np.stack(clouds)).to(dev)
         renderer = MVRenderer(V, H, pc_rendering=True, object_color="white", background_color="white",
                               points_radius=0.006, rotation_check=args.rotation_check, strip_rows=args.strip_rows).eval()
     else:
         vl, fl = [], []
         for i in range(B):
-            v, f = syn.synthetic_mesh(args.tier, rank * B + i)
+            v, f = syn.synthetic_mesh(args.tier, seed0 + i)
             vl.append(torch.from_numpy(v))
             fl.append(torch.from_numpy(f))
             nv_list.append(len(v))
@@ -204,8 +244,11 @@ def main():
         if args.host_meshes:
             packed = [Meshes([v], [f]) for v, f in zip(vl, fl)]  # list of single-mesh objects on the CPU, as collate_fn yields
         light = "relative" if args.workload == "mesh_fwdbwd" else "fixed"
+        extra = {}
+        if soft:   # SoftPhongShader as PyTorch3D's tutorials configure it: sigma 1e-4, blur_radius = log(1/1e-4 - 1) sigma, K = 4
+            extra = dict(shader="soft_phong", faces_per_pixel=4, sigma=1e-4, gamma=1e-4, blur_radius=float(np.log(1.0 / 1e-4 - 1.0) * 1e-4))
         renderer = MVRenderer(V, H, pc_rendering=False, object_color="white", background_color="white",
-                              light_direction=light, rotation_check=args.rotation_check, strip_rows=args.strip_rows).eval()
+                              light_direction=light, rotation_check=args.rotation_check, strip_rows=args.strip_rows, **extra).eval()
     if args.workload == "mesh_fwdbwd":
         rng = np.random.default_rng(1)
         azim = (azim + torch.from_numpy(rng.uniform(-5, 5, (B, V)).astype(np.float32)).to(dev)).requires_grad_(True)
@@ -214,7 +257,7 @@ def main():
         gen = torch.Generator(device=dev).manual_seed(2)
         upstream = torch.randn(B, V, 3, H, W, device=dev, generator=gen)
 
-    def step():
+    def render():
         if args.workload == "mesh_fwdbwd":
             azim.grad = elev.grad = dist_t.grad = None
             img, _ = renderer(packed, None, azim, elev, dist_t)
@@ -226,55 +269,69 @@ def main():
         with torch.no_grad():
             return renderer(packed, None, azim, elev, dist_t)[0]
 
+    # c5 on several GPUs: the step is the local render + the all-gather of the rendered views (north_star)
+    gather_in_step = fixed_total and world > 1 and not args.no_gather
+    if gather_in_step:
+        from mvtn_amd.distributed import all_gather_views, shard_counts
+        counts = shard_counts(64, world)
+
+        def step():
+            return all_gather_views(render(), counts)
+    else:
+        step = render
+
     def barrier():
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    F.set_forward_pieces(args.forward_pieces)
+    # untimed: max(W, 50) steps in all — a short --warmup (the driver passes 5) leaves clocks, caches and the allocator cold
+    prewarm = max(0, 50 - args.warmup)
+    for _ in range(prewarm + args.warmup):
         out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    n_views_total = B * V * world
+    elapsed = timed(step, args.steps, barrier, dist_on, dev)
+    out = render()
     value = n_views_total * args.steps / elapsed
 
-    # ---- dominant-kernel duration, HIP events on the launch stream, same K steps ---------------------
-    kind = {"mesh_fwd": 0, "points_fwd": 1, "mesh_fwdbwd": 0}[args.workload]
+    # ---- dominant-kernel duration, HIP events on the launch stream, same K steps.  The forward is issued as ONE piece here
+    # (mvr_set_forward_pieces(1)): a launch then covers the whole batch, as `algorithmic_bytes_per_launch` assumes and as
+    # in earlier rounds; the timed steps above may have issued it in pieces on two streams (`forward_pieces`).
+    kind = 3 if soft else {"mesh_fwd": 0, "points_fwd": 1, "mesh_fwdbwd": 0}[args.workload]
+    F.set_forward_pieces(1)
+    for _ in range(3):
+        render()
     lib.mvr_profile_begin()
     for _ in range(args.steps):
-        out = step()
-    ms = (ctypes.c_double * 3)()
-    cnt = (ctypes.c_int32 * 3)()
+        render()
+    ms = (ctypes.c_double * 8)()
+    cnt = (ctypes.c_int32 * 8)()
     lib.mvr_profile_end(ms, cnt)
     torch.cuda.synchronize()
+    F.set_forward_pieces(args.forward_pieces)
     kern_ms = ms[kind] / max(1, cnt[kind])
     alg = algorithmic_bytes("mesh_fwd" if args.workload == "mesh_fwdbwd" else args.workload, B, V, H, W, nv_list, nf_list, P)
+    if soft:
+        alg += B * V * H * W * 4     # the alpha plane of the RGBA frames
     achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     # HBM traffic of the dominant kernel: PMC passes of the same command, committed under profiles/ (FETCH_SIZE / WRITE_SIZE
     # cannot be read inside this process); `from_profiles` names the file so that a stale number is visible as such
     traffic, traffic_src = None, None
-    for tpath in ([] if c5 else sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % args.workload)))[-1:]):
+    for tpath in ([] if (c5 or soft) else sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % args.workload)))[-1:]):
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             traffic_src = os.path.relpath(tpath, ROOT)
         except Exception:
             traffic = None
-    kname = ["k_mesh_raster_fast", "k_points_raster_shade", "k_mesh_raster_fast"][kind]
+    kname = "k_mesh_soft_forward" if soft else ["k_mesh_raster_fast", "k_points_raster_shade", "k_mesh_raster_fast"][kind]
     roofline = {"bound": "hbm", "kernel": kname,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_from_profiles": traffic_src, "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
-                "launches_timed": int(cnt[kind])}
-    if args.workload == "mesh_fwdbwd" and cnt[2] > 0:
-        roofline["backward_kernel_ms"] = ms[2] / cnt[2]
+                "launches_timed": int(cnt[kind]),
+                "launch": "the whole batch in one launch (mvr_set_forward_pieces(1)) on the stream it is launched on"}
+    if args.workload == "mesh_fwdbwd" and cnt[4 if soft else 2] > 0:
+        roofline["backward_kernel_ms"] = ms[4 if soft else 2] / cnt[4 if soft else 2]
     # what actually bounds the mesh kernels (profiles/README.md): VALU issue.  A wave64 VALU instruction holds its SIMD for
     # 4 cycles, so instructions x 4 / 1024 SIMDs is the kernel's VALU floor in cycles; against the LIVE kernel time (at the
     # 2.07 GHz the counters show under this load) it gives the share of the launch the VALUs were issuing.  The instruction
@@ -283,12 +340,27 @@ def main():
         import glob
         sqp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.json")))[-1]
         k = json.load(open(sqp)).get(kname)
-        if k and k.get("SQ_INSTS_VALU") and kern_ms > 0 and args.workload != "points_fwd" and not c5:
+        if k and k.get("SQ_INSTS_VALU") and kern_ms > 0 and args.workload != "points_fwd" and not c5 and not soft:
             floor_ms = k["SQ_INSTS_VALU"] * 4.0 / 1024.0 / 2.07e9 * 1e3
             roofline["valu"] = {"wave_instructions": k["SQ_INSTS_VALU"], "issue_floor_ms": floor_ms, "frac": floor_ms / kern_ms,
                                 "from_profiles": os.path.relpath(sqp, ROOT)}
     except Exception:
         pass
+
+    # ---- beside `value`: the render alone when the step carries the gather; the same forward as ONE piece on one stream
+    beside = {}
+    if gather_in_step:
+        t_r = timed(render, args.steps, barrier, dist_on, dev)
+        beside["render_only"] = {"views_per_s": n_views_total * args.steps / t_r, "ms_per_step": t_r / args.steps * 1e3,
+                                 "note": "the local shards rendered, no all-gather (what data-parallel training consumes)"}
+    if args.workload == "mesh_fwd" and not soft and not args.host_meshes and not args.no_pipelined:
+        F.set_forward_pieces(1)
+        for _ in range(10):
+            render()
+        t_1 = timed(render, args.steps, barrier, dist_on, dev)
+        F.set_forward_pieces(args.forward_pieces)
+        beside["one_piece"] = {"views_per_s": B * V * world * args.steps / t_1, "ms_per_step": t_1 / args.steps * 1e3,
+                               "note": "the same forward as one pre-pass + one rasteriser launch on the caller's stream (no gather)"}
 
     # ---- beside `value`: the same K forwards issued round-robin on two streams (mvtn_amd.pipeline.StreamPipeline):
     # independent batches in flight, the pre-pass of one fills the rasteriser tail of the other.  An inference-time
@@ -298,25 +370,20 @@ def main():
         from mvtn_amd.pipeline import StreamPipeline
         pipe = StreamPipeline(2, dev)
         for _ in range(min(args.warmup, 50)):
-            pipe.submit(step, inputs_ready=True)
+            pipe.submit(render, inputs_ready=True)
         pipe.join()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.submit(step, inputs_ready=True)
-        pipe.join()
-        barrier()
-        tp = time.perf_counter() - t0
-        if dist_on:
-            t = torch.tensor([tp], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tp = float(t.item())
-        pipelined = {"streams": 2, "views_per_s": n_views_total * args.steps / tp, "ms_per_step": tp / args.steps * 1e3}
 
-    # ---- C3: the same training step captured once in a HIP graph (torch.cuda.CUDAGraph) and replayed K times.
-    # The eager step above costs the host ~0.2 ms of Python / autograd dispatch, about what the GPU needs for it, so
-    # that leg depends on the box's host cores; a replay costs the host one call.  The replay is C3's `value`, the
-    # eager leg is reported beside it (`eager_python`).
+        def piped_all():
+            for _ in range(args.steps):
+                pipe.submit(render, inputs_ready=True)
+            pipe.join()
+        tp = timed(piped_all, 1, barrier, dist_on, dev)
+        pipelined = {"streams": 2, "views_per_s": B * V * world * args.steps / tp, "ms_per_step": tp / args.steps * 1e3}
+
+    # ---- C3, beside `value` (which stays the step issued eagerly from Python, as in every round): the same training step
+    # captured once in a HIP graph (torch.cuda.CUDAGraph) and replayed K times.  The eager step costs the host ~0.2 ms of
+    # Python / autograd dispatch, about what the GPU needs for it, so on slow host cores `value` measures the host; a
+    # replay costs the host one call.
     graphed = None
     if args.workload == "mesh_fwdbwd" and not args.host_meshes and not args.no_pipelined:
         try:
@@ -337,120 +404,120 @@ def main():
                 g_keep = gstep()
             for _ in range(min(args.warmup, 50)):
                 graph.replay()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                graph.replay()
-            barrier()
-            tg_ = time.perf_counter() - t0
-            if dist_on:
-                t = torch.tensor([tg_], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                tg_ = float(t.item())
-            graphed = {"views_per_s": n_views_total * args.steps / tg_, "ms_per_step": tg_ / args.steps * 1e3}
+            tg_ = timed(graph.replay, args.steps, barrier, dist_on, dev)
+            graphed = {"views_per_s": n_views_total * args.steps / tg_, "ms_per_step": tg_ / args.steps * 1e3,
+                       "note": "the captured step replayed (torch.cuda.CUDAGraph): same kernels, one host call per step"}
             del graph, g_keep
         except Exception as exc:   # (a capture failure must not lose the measured line)
             graphed = {"error": str(exc)[:200]}
 
-    # ---- optional: the all-gather of rendered views the north_star names (not part of `value`) --------
+    # ---- the all-gather of rendered views the north_star names: inside `value` for c5 on several GPUs (above); for the
+    # weak-scaling workloads timed here, beside `value`
     gather = None
     if dist_on and not args.no_gather:
         from mvtn_amd.distributed import all_gather_views
-        img = out.detach()
-        for _ in range(3):
-            all_gather_views(img)
-        barrier()
-        t0 = time.perf_counter()
+        gather = {"bytes_gathered_per_rank": int(out.numel() * 4 * world) if not fixed_total else int(64 * V * 3 * H * W * 4)}
         reps = max(3, min(20, args.steps))
-        for _ in range(reps):
-            step_img = step().detach()
-            all_gather_views(step_img)
-        barrier()
-        tg = time.perf_counter() - t0
-        t = torch.tensor([tg], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        gather = {"views_per_s_with_allgather": n_views_total * reps / float(t.item()),
-                  "bytes_gathered_per_rank": int(img.numel() * 4 * world)}
-        if args.exchange_pieces > 0 and args.workload != "mesh_fwdbwd" and not args.host_meshes:
-            # the same exchange hidden behind the rendering: the shard is rendered in 2 pieces, piece c travels (direct
+        if gather_in_step:
+            gather["inside_value"] = True
+        else:
+            img = out.detach()
+            for _ in range(3):
+                all_gather_views(img)
+
+            def with_gather():
+                all_gather_views(render().detach())
+            tg = timed(with_gather, reps, barrier, dist_on, dev)
+            gather["views_per_s_with_allgather"] = n_views_total * reps / tg
+        chunks = args.exchange_pieces if args.exchange_pieces >= 0 else (2 if fixed_total else 0)
+        if chunks > 0 and args.workload != "mesh_fwdbwd" and not args.host_meshes:
+            # the same exchange hidden behind the rendering: the shard is rendered in pieces, piece c travels (direct
             # sends to every peer, landing in place) while piece c+1 renders (mvtn_amd.distributed.render_sharded_overlapped)
-            from mvtn_amd.distributed import _chunk_bounds, render_sharded_overlapped, shard_range
-            chunks = args.exchange_pieces
-            lo, hi = shard_range(B * world, world, rank)
-            azg, elg, dg = (x.detach().repeat(world, 1) for x in (azim, elev, dist_t))
+            from mvtn_amd.distributed import _chunk_bounds, render_sharded_overlapped
+            Btot = 64 if fixed_total else B * world
+            lo, hi = shard_range(Btot, world, rank)
+            if fixed_total:
+                azg, elg, dg = (torch.from_numpy(np.tile(x, (Btot, 1))).to(dev) for x in (az, el, di))
+            else:
+                azg, elg, dg = (x.detach().repeat(world, 1) for x in (azim, elev, dist_t))
             pieces = ptsg = None
             if args.workload == "points_fwd":
-                ptsg = torch.zeros(B * world, P, 3, device=dev)
+                ptsg = torch.zeros(Btot, P, 3, device=dev)
                 ptsg[lo:hi] = points
             else:
-                pieces = [PackedMeshes.from_meshes(Meshes(vl[a - lo:b - lo], fl[a - lo:b - lo]), dev) for a, b in _chunk_bounds(lo, hi, chunks)]
+                pieces = [PackedMeshes.from_meshes(Meshes(vl[a - lo:b - lo], fl[a - lo:b - lo]), dev) if b > a else None
+                          for a, b in _chunk_bounds(lo, hi, chunks)]
 
             def overlapped():
                 return render_sharded_overlapped(renderer, None, ptsg, azg, elg, dg, chunks=chunks, packed_pieces=pieces)[0]
             for _ in range(3):
                 overlapped()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                overlapped()
-            barrier()
-            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gather["views_per_s_with_overlapped_exchange"] = n_views_total * reps / float(t.item())
+            to = timed(overlapped, reps, barrier, dist_on, dev)
+            gather["views_per_s_with_overlapped_exchange"] = n_views_total * reps / to
             gather["exchange_pieces"] = chunks
 
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, V)
         # second half of BASELINE.json's metric: max pixel |delta| vs the PyTorch3D-semantics oracle
-        # (first 2 objects of the batch, all views; the oracle is the checker, never the thing timed)
+        # (first 2 objects of rank 0's shard, all views; the oracle is the checker, never the thing timed)
         from oracle import oracle as orc
-        nb = min(2, B)
+        nb = min(1 if soft else 2, B)
         img = out.detach()[:nb].cpu().numpy()
         a_, e_, d_ = (x.detach()[:nb].cpu().numpy() for x in (azim, elev, dist_t))
         if args.workload == "points_fwd":
             want = orc.render_points(points[:nb].cpu().numpy(), a_, e_, d_, H, radius=0.006, obj_color=(0.99999,) * 3,
                                      bg_color=(0.99999,) * 3, return_fragments=False)
+            parity = float(np.abs(img - want["images"]).max())
+        elif soft:
+            parity = soft_parity(orc, vl[0].numpy(), fl[0].numpy(), a_, e_, d_, H, renderer, img)
         else:
-            vl = [vl[i].numpy() for i in range(nb)]
-            fl = [fl[i].numpy() for i in range(nb)]
+            vln = [vl[i].numpy() for i in range(nb)]
+            fln = [fl[i].numpy() for i in range(nb)]
             ld = orc.camera_position(a_, e_, d_) if args.workload == "mesh_fwdbwd" else ((0.0, 1.0, 0.0),)
-            want = orc.render_meshes(vl, fl, a_, e_, d_, H, light_dir=ld, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3,
+            want = orc.render_meshes(vln, fln, a_, e_, d_, H, light_dir=ld, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3,
                                      return_fragments=False)
-        parity = float(np.abs(img - want["images"]).max())
+            parity = float(np.abs(img - want["images"]).max())
 
     if rank == 0:
+        if fixed_total:
+            wl = "C5: 64 tier-L meshes x %d spherical views in total, %dx%d, mesh render fwd%s; %d..%d objects per GPU" % (
+                V, H, W, " + RCCL all-gather of the rendered views" if gather_in_step else "", 64 // world, -(-64 // world))
+        elif c5:
+            wl = "C5 (one GPU's share): B=%d tier-L meshes x %d spherical views, %dx%d, mesh render fwd" % (B, V, H, W)
+        elif soft:
+            wl = "C3 shape through SoftPhongShader: B=%d tier-%s meshes x %d jittered views, %dx%d, faces_per_pixel 4, sigma 1e-4, fwd+bwd" % (B, args.tier, V, H, W)
+        else:
+            wl = {"mesh_fwd": "C2: B=%d tier-%s meshes x %d spherical views, %dx%d, mesh render fwd" % (B, args.tier, V, H, W),
+                  "mesh_fwdbwd": "C3: B=%d tier-%s meshes x %d jittered views, %dx%d, fwd+bwd (grad wrt azim/elev/dist, relative light)" % (B, args.tier, V, H, W),
+                  "points_fwd": "C4: B=%d clouds x 2048 pts x %d views, %dx%d, point render fwd" % (B, V, H, W)}[args.workload]
         line = {
-            "metric": ("rendered views/sec (224x224, 20 views/obj)" if c5 else "rendered views/sec (224x224, 12 views/obj)") if args.workload != "points_fwd" else "rendered views/sec (224x224 point clouds, 20 views/obj)",
+            "metric": "rendered views/sec (224x224 point clouds, 20 views/obj)" if args.workload == "points_fwd" else
+                      "rendered views/sec (224x224, %d views/obj)" % V,
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if fixed_total else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C5 (per GPU): B=%d tier-L meshes x %d spherical views, %dx%d, mesh render fwd" % (B, V, H, W) if c5 else
-                                   {"mesh_fwd": "C2: B=%d tier-%s meshes x %d spherical views, %dx%d, mesh render fwd" % (B, args.tier, V, H, W),
-                                    "mesh_fwdbwd": "C3: B=16 tier-%s meshes x 12 jittered views, %dx%d, fwd+bwd (grad wrt azim/elev/dist, relative light)" % (args.tier, H, W),
-                                    "points_fwd": "C4: B=20 clouds x 2048 pts x 20 views, %dx%d, point render fwd" % (H, W)}[args.workload],
+            "config": {"workload": wl,
                        "objects_per_gpu": B, "views_per_object": V, "image_size": H, "rotation_check": args.rotation_check,
                        "inputs": "CPU meshes packed + copied every step" if args.host_meshes else "resident in HBM",
-                       "parallelism": "objects sharded over %d GPU(s), no data-path collective" % world},
+                       "issue": "eager: one MVRenderer.forward%s per step from Python" % (" + backward" if args.workload == "mesh_fwdbwd" else ""),
+                       "forward_pieces": args.forward_pieces or "auto",
+                       "untimed_steps_before_the_timed_region": prewarm + args.warmup,
+                       "parallelism": ("objects sharded over %d GPU(s); " % world) +
+                                      ("one RCCL all-gather of the rendered views per step" if gather_in_step else "no data-path collective")},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "max_pixel_err_vs_oracle": parity,
         }
+        line.update(beside)
         if gather:
             line["allgather"] = gather
         if dist_on:
             line["world_size_seen_by_rccl"] = dist.get_world_size()
         if pipelined:
             line["two_streams"] = pipelined
-        if graphed and "views_per_s" in graphed:
-            # C3's `value`: the training step as a deployment issues it — captured once in a HIP graph, replayed K times (the
-            # same kernels on the same inputs; the timed region above issued them eagerly from Python, which costs the host
-            # about as long as the GPU needs: on a slow host core that leg measures the host).  Both are in the line.
-            line["eager_python"] = {"views_per_s": value, "ms_per_step": elapsed / args.steps * 1e3}
-            line["value"], line["ms_per_step"] = graphed["views_per_s"], graphed["ms_per_step"]
-            line["config"]["issue"] = "HIP graph replay of the captured step (torch.cuda.CUDAGraph); eager issue: eager_python"
-        elif graphed:
+        if graphed:
             line["hip_graph_replay"] = graphed
         sys.stdout.flush()
         try:
@@ -461,7 +528,18 @@ def main():
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
     if dist_on:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def soft_parity(orc, v, f, az, el, di, H, renderer, img):
+    """max |RGB difference| of object 0's views against the oracle's SoftPhongShader restatement (bounded: first 2 views)."""
+    nv = min(2, az.shape[1])
+    ld = orc.camera_position(az[:, :nv], el[:, :nv], di[:, :nv])
+    want = orc.render_meshes_soft([v], [f], az[:, :nv], el[:, :nv], di[:, :nv], H, light_dir=ld, obj_color=(0.99999,) * 3,
+                                  bg_color=(0.99999,) * 3, blur_radius=renderer.blur_radius, faces_per_pixel=renderer.faces_per_pixel,
+                                  sigma=renderer.sigma, gamma=renderer.gamma)
+    return float(np.abs(img[:, :nv] - want["images"][:, :nv, 0:3]).max())
 
 
 if __name__ == "__main__":

@@ -69,6 +69,8 @@ PROTOTYPES = {
     "mvr_pack_meshes_layout": (ctypes.c_int, [ctypes.c_int32, _vp, _vp, _PL]),
     "mvr_pack_meshes_host": (ctypes.c_int, [_PL, _vp, _vp, _vp, _vp, _vp]),
     "mvr_version": (ctypes.c_int, []),
+    "mvr_source_hash": (ctypes.c_char_p, []),
+    "mvr_set_forward_pieces": (ctypes.c_int, [ctypes.c_int32]),
     "mvr_last_error": (ctypes.c_char_p, []),
     "mvr_render_mesh_views_forward": (ctypes.c_int, [_MB, _MP, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                                      ctypes.c_uint64] + [ctypes.c_void_p] * 11 + [ctypes.c_size_t, ctypes.c_void_p]),
@@ -112,18 +114,30 @@ def load():
     if _LIB is not None:
         return _LIB
     path = lib_path()
+    unverified = False
     if not os.environ.get("MVR_LIB") and not _build.is_current():
         # the in-tree library is missing or was built from other sources than the ones on disk: (re)build it now — hipcc
         # cross-compiles without a GPU; concurrent ranks serialise on a file lock and only the first one compiles
         try:
             _build.build_hip()
         except Exception as e:  # noqa: BLE001
-            raise ImportError(
-                "mvtn_amd: %s is missing or stale and could not be built (%s) — the HIP extension is the only rendering path "
-                "(no CPU fallback).  Build it with `python -c 'import __graft_entry__ as g; g.build()'`." % (path, e))
+            # a deployed tree may ship the library without its side file, on a node without hipcc or with a read-only
+            # package directory: the library carries the hash of its sources itself (mvr_source_hash) — checked below
+            if not os.path.exists(path):
+                raise ImportError(
+                    "mvtn_amd: %s is missing and could not be built (%s) — the HIP extension is the only rendering path "
+                    "(no CPU fallback).  Build it with `python -c 'import __graft_entry__ as g; g.build()'`." % (path, e))
+            unverified = True
     if not os.path.exists(path):
         raise ImportError("mvtn_amd: %s does not exist" % path)
     lib = ctypes.CDLL(path)
+    if unverified:
+        lib.mvr_source_hash.restype = ctypes.c_char_p
+        have = (lib.mvr_source_hash() or b"").decode()
+        if have != _build.source_hash():
+            import warnings
+            warnings.warn("mvtn_amd: %s was built from other sources than the ones beside it (library %s..., tree %s...) and could "
+                          "not be rebuilt here; loading it as it is" % (path, have[:12], _build.source_hash()[:12]), RuntimeWarning)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res

@@ -53,11 +53,19 @@ def _hash_path(lib):
     return lib + ".srchash"
 
 
+def source_hash():
+    """The hash the product library carries (mvr_source_hash()) when it was built from the sources on disk."""
+    return _src_hash(_sources(), HIPCC_FLAGS)
+
+
 def is_current(lib=None):
     """True when `lib` (default: the product library) was built from exactly the sources on disk."""
     lib = lib or LIB_PATH
     try:
-        return os.path.exists(lib) and open(_hash_path(lib)).read().strip() == _src_hash(_sources(), HIPCC_FLAGS)
+        if not os.path.exists(lib):
+            return False
+        with open(_hash_path(lib)) as f:
+            return f.read().strip() == source_hash()
     except OSError:
         return False
 
@@ -97,7 +105,8 @@ def _compile(srcs, LIB_PATH, extra, verbose):
     tmp_lib = "%s.tmp.%d" % (LIB_PATH, os.getpid())
     pack_o = "%s.pack.%d.o" % (LIB_PATH, os.getpid())
     cmds = [["g++", "-O3", "-std=c++17", "-fPIC", "-fvisibility-inlines-hidden", "-c", "-o", pack_o, srcs[3]],
-            [hipcc] + HIPCC_FLAGS + extra + ["-o", tmp_lib, srcs[0], srcs[4], "-Wl," + pack_o]]
+            [hipcc] + HIPCC_FLAGS + extra + ['-DMVR_SRC_HASH="%s"' % _src_hash(srcs, HIPCC_FLAGS), "-o", tmp_lib, srcs[0], srcs[4],
+                                               "-Wl," + pack_o]]
     try:
         for cmd in cmds:
             r = subprocess.run(cmd, capture_output=True, text=True)

@@ -65,13 +65,18 @@ def all_gather_views(local_images, counts=None, group=None):
     return _AllGatherViews.apply(local_images, list(counts), group)
 
 
+def _channels(renderer):
+    """Channels of the renderer's images: the soft shaders return RGBA with `return_alpha` (mvtn_amd/renderer.py)."""
+    return 4 if (getattr(renderer, "return_alpha", False) and getattr(renderer, "shader", "hard_phong") != "hard_phong") else 3
+
+
 def _image_tail(renderer, azim, group, have_local, local_tail):
     """(V, 3, H, W) of the renderer's output for ranks that render nothing.  MVRenderer knows it (`image_size`); for any
     other callable the lowest rank that did render broadcasts its tail — every rank takes this branch together because
     the shard sizes are a function of (B, world) only."""
     S = getattr(renderer, "image_size", None)
     if S is not None:
-        return (azim.shape[1], 3, int(S), int(S))
+        return (azim.shape[1], _channels(renderer), int(S), int(S))
     world = dist.get_world_size(group)
     t = torch.tensor(list(local_tail) if have_local else [0, 0, 0, 0], dtype=torch.int64, device=azim.device)
     allt = [torch.zeros_like(t) for _ in range(world)]
@@ -148,7 +153,7 @@ def render_sharded_overlapped(renderer, meshes, points, azim, elev, dist_, color
     # renderers in tests) from the first rank's first object — no throw-away render on the GPU path
     tail = None
     if getattr(renderer, "image_size", None) is not None:
-        tail = (azim.shape[1], 3, int(renderer.image_size), int(renderer.image_size))
+        tail = (azim.shape[1], _channels(renderer), int(renderer.image_size), int(renderer.image_size))
     elif min(hi - lo for lo, hi in ranges) == 0 or min(b - a for pr in pieces for a, b in pr) == 0:
         with torch.no_grad():
             probe = renderer(None if meshes is None else [meshes[0]], None if points is None else points[:1],
