@@ -50,7 +50,6 @@ def parse():
                          "meshes x 20 views in total, sharded over the GPUs, the all-gather inside the step; c5_per_gpu = 8 such "
                          "meshes per GPU (one GPU's share at N = 8; weak scaling); soft_fwdbwd = C3's shape through the "
                          "SoftPhongShader path (K = 4, sigma = 1e-4)")
-    ap.add_argument("--forward-pieces", type=int, default=0, help="mvr_set_forward_pieces for the timed steps (0 = automatic)")
     ap.add_argument("--batch", type=int, default=0, help="objects per GPU (default: the BASELINE config's)")
     ap.add_argument("--views", type=int, default=0)
     ap.add_argument("--image-size", type=int, default=224)
@@ -189,7 +188,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, functional as F, synthetic as syn
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib, synthetic as syn
     from mvtn_amd.distributed import shard_range
     lib = _lib.load()
 
@@ -286,7 +285,6 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    F.set_forward_pieces(args.forward_pieces)
     # untimed: max(W, 50) steps in all — a short --warmup (the driver passes 5) leaves clocks, caches and the allocator cold
     prewarm = max(0, 50 - args.warmup)
     for _ in range(prewarm + args.warmup):
@@ -295,13 +293,8 @@ def main():
     out = render()
     value = n_views_total * args.steps / elapsed
 
-    # ---- dominant-kernel duration, HIP events on the launch stream, same K steps.  The forward is issued as ONE piece here
-    # (mvr_set_forward_pieces(1)): a launch then covers the whole batch, as `algorithmic_bytes_per_launch` assumes and as
-    # in earlier rounds; the timed steps above may have issued it in pieces on two streams (`forward_pieces`).
+    # ---- dominant-kernel duration, HIP events on the launch stream, same K steps
     kind = 3 if soft else {"mesh_fwd": 0, "points_fwd": 1, "mesh_fwdbwd": 0}[args.workload]
-    F.set_forward_pieces(1)
-    for _ in range(3):
-        render()
     lib.mvr_profile_begin()
     for _ in range(args.steps):
         render()
@@ -309,7 +302,6 @@ def main():
     cnt = (ctypes.c_int32 * 8)()
     lib.mvr_profile_end(ms, cnt)
     torch.cuda.synchronize()
-    F.set_forward_pieces(args.forward_pieces)
     kern_ms = ms[kind] / max(1, cnt[kind])
     alg = algorithmic_bytes("mesh_fwd" if args.workload == "mesh_fwdbwd" else args.workload, B, V, H, W, nv_list, nf_list, P)
     if soft:
@@ -328,8 +320,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": kname,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_from_profiles": traffic_src, "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
-                "launches_timed": int(cnt[kind]),
-                "launch": "the whole batch in one launch (mvr_set_forward_pieces(1)) on the stream it is launched on"}
+                "launches_timed": int(cnt[kind])}
     if args.workload == "mesh_fwdbwd" and cnt[4 if soft else 2] > 0:
         roofline["backward_kernel_ms"] = ms[4 if soft else 2] / cnt[4 if soft else 2]
     # what actually bounds the mesh kernels (profiles/README.md): VALU issue.  A wave64 VALU instruction holds its SIMD for
@@ -347,20 +338,12 @@ def main():
     except Exception:
         pass
 
-    # ---- beside `value`: the render alone when the step carries the gather; the same forward as ONE piece on one stream
+    # ---- beside `value`: the render alone when the step carries the gather
     beside = {}
     if gather_in_step:
         t_r = timed(render, args.steps, barrier, dist_on, dev)
         beside["render_only"] = {"views_per_s": n_views_total * args.steps / t_r, "ms_per_step": t_r / args.steps * 1e3,
                                  "note": "the local shards rendered, no all-gather (what data-parallel training consumes)"}
-    if args.workload == "mesh_fwd" and not soft and not args.host_meshes and not args.no_pipelined:
-        F.set_forward_pieces(1)
-        for _ in range(10):
-            render()
-        t_1 = timed(render, args.steps, barrier, dist_on, dev)
-        F.set_forward_pieces(args.forward_pieces)
-        beside["one_piece"] = {"views_per_s": B * V * world * args.steps / t_1, "ms_per_step": t_1 / args.steps * 1e3,
-                               "note": "the same forward as one pre-pass + one rasteriser launch on the caller's stream (no gather)"}
 
     # ---- beside `value`: the same K forwards issued round-robin on two streams (mvtn_amd.pipeline.StreamPipeline):
     # independent batches in flight, the pre-pass of one fills the rasteriser tail of the other.  An inference-time
@@ -502,7 +485,6 @@ def main():
                        "objects_per_gpu": B, "views_per_object": V, "image_size": H, "rotation_check": args.rotation_check,
                        "inputs": "CPU meshes packed + copied every step" if args.host_meshes else "resident in HBM",
                        "issue": "eager: one MVRenderer.forward%s per step from Python" % (" + backward" if args.workload == "mesh_fwdbwd" else ""),
-                       "forward_pieces": args.forward_pieces or "auto",
                        "untimed_steps_before_the_timed_region": prewarm + args.warmup,
                        "parallelism": ("objects sharded over %d GPU(s); " % world) +
                                       ("one RCCL all-gather of the rendered views per step" if gather_in_step else "no data-path collective")},

@@ -136,14 +136,6 @@ const char *mvr_last_error(void);
  * recognise a library that does not belong to the tree beside it without a side file. */
 const char *mvr_source_hash(void);
 
-/* How mvr_render_mesh_views_forward / mvr_render_meshes_forward issue a batch (replaces nothing in the reference: PyTorch3D
- * runs models/renderer.py:84-107 as one serial sequence of launches).  The batch is rendered as `pieces` ranges of meshes,
- * alternating between the caller's stream and ONE library-owned side stream, forked and joined with events (no host
- * synchronisation; capturable in a HIP graph): the pre-pass of one piece (one workgroup per view) runs beside the
- * rasteriser of the previous piece.  Results are identical for every value.  0 = automatic (the default; environment
- * MVR_FWD_PIECES overrides it at load time): 1 for small batches, 2 or 4 when every piece still fills the GPU; 1..8 = fixed. */
-int mvr_set_forward_pieces(int32_t pieces);
-
 /* Measurement aid (bench.py): between begin and end, the dominant kernel of each path is bracketed by
  * HIP events recorded on the stream it is launched on.  mvr_profile_end synchronises on those events and
  * returns, per kind {0: mesh raster+shade forward, 1: points raster+shade forward, 2: mesh backward, 3: soft mesh

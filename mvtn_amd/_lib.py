@@ -70,7 +70,6 @@ PROTOTYPES = {
     "mvr_pack_meshes_host": (ctypes.c_int, [_PL, _vp, _vp, _vp, _vp, _vp]),
     "mvr_version": (ctypes.c_int, []),
     "mvr_source_hash": (ctypes.c_char_p, []),
-    "mvr_set_forward_pieces": (ctypes.c_int, [ctypes.c_int32]),
     "mvr_last_error": (ctypes.c_char_p, []),
     "mvr_render_mesh_views_forward": (ctypes.c_int, [_MB, _MP, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                                      ctypes.c_uint64] + [ctypes.c_void_p] * 11 + [ctypes.c_size_t, ctypes.c_void_p]),

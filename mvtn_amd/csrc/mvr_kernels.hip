@@ -94,8 +94,6 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // ---- optional in-library kernel timing (bench.py roofline leg) -------------------------------------
 // When enabled, the dominant kernel of each path is bracketed by HIP events recorded on the SAME
 // stream it is launched on.  Disabled (the default) nothing below runs in the launch path.
-#include <atomic>
-#include <mutex>
 #include <vector>
 #include <utility>
 enum { PROF_MESH_FWD = 0, PROF_POINTS_FWD = 1, PROF_MESH_BWD = 2, PROF_SOFT_FWD = 3, PROF_SOFT_BWD = 4, PROF_MESH_PREPASS = 5, PROF_KINDS = 8 };   // (6, 7: unused)

@@ -124,13 +124,6 @@ def camera_position_from_spherical_angles(distance, elevation, azimuth):
 # mesh path
 # ---------------------------------------------------------------------------------------------
 
-def set_forward_pieces(pieces=0):
-    """How the hard mesh forward issues a batch (`mvr_set_forward_pieces`): as `pieces` ranges of meshes alternating between
-    the caller's stream and the library's side stream, so that one piece's pre-pass runs beside the previous piece's
-    rasteriser.  0 = automatic (default), 1 = one launch pair on the caller's stream, up to 8.  Results never depend on it."""
-    _lib.check(_lib.load().mvr_set_forward_pieces(int(pieces)), "set_forward_pieces")
-
-
 def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backfaces=False, perspective_correct=True,
                 fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, strip_rows=0, exact_raster=False, z_clip=None,
                 gather_backward=False, normalize=None):

@@ -1,6 +1,5 @@
-"""-m gpu, round 3: the forward issued in pieces on two streams (results never depend on the piece count), files ->
-`io.mesh_from_file` -> `MVRenderer` against the oracle, rendered views -> `save_grid` -> PNG decode
-against the tensor (row f2)."""
+"""-m gpu, round 3: files -> `io.mesh_from_file` -> `MVRenderer` against the oracle, rendered views ->
+`save_grid` -> PNG decode against the tensor (row f2)."""
 import os
 
 import numpy as np
@@ -30,137 +29,6 @@ def _views(B, V, seed):
     el = np.tile(el, (B, 1)) + rng.uniform(-5, 5, (B, V))
     di = np.tile(di, (B, 1)) + rng.uniform(-0.1, 0.1, (B, V))
     return az.astype(np.float32), el.astype(np.float32), di.astype(np.float32)
-
-
-@pytest.fixture
-def pieces_reset():
-    from mvtn_amd import functional as F
-    yield F
-    F.set_forward_pieces(0)
-
-
-@pytest.mark.parametrize("specs,V,size,light", [
-    ([("M", 0), ("S", 1), ("M", 2), ("L", 3), ("S", 4)], 6, 96, "relative"),     # ragged batch, 5 objects: pieces of 1-3 meshes
-    ([("M", k) for k in range(8)], 12, 224, "fixed"),                            # half of C2
-])
-def test_forward_pieces_do_not_change_results(pieces_reset, specs, V, size, light):
-    """mvr_set_forward_pieces: images, pixel -> face maps, cameras and gradients are IDENTICAL for 1 / 2 / 3 / 4 / 8 pieces and
-    for the automatic choice (each piece's pre-pass evaluates the look-at of all views; the workspace is indexed by
-    global mesh / view numbers)."""
-    F = pieces_reset
-    from mvtn_amd import MVRenderer, Meshes, PackedMeshes
-    dev = _dev()
-    vl, fl = [], []
-    for tier, seed in specs:
-        v, f = syn.synthetic_mesh(tier, seed)
-        vl.append(v); fl.append(f)
-    B = len(specs)
-    packed = PackedMeshes.from_meshes(Meshes(vl, fl), dev)
-    az, el, di = _views(B, V, 7)
-    r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction=light).eval()
-    G = torch.randn(B, V, 3, size, size, generator=torch.Generator().manual_seed(3)).to(dev)
-    ref = None
-    for pieces in (1, 2, 3, 4, 8, 0):
-        F.set_forward_pieces(pieces)
-        a, e, d = (_t(x).requires_grad_(True) for x in (az, el, di))
-        img, cams = r(packed, None, a, e, d)
-        grads = torch.autograd.grad((img * G).sum(), (a, e, d))
-        with torch.no_grad():
-            img2, _ = r(packed, None, a.detach(), e.detach(), d.detach())     # the inference path (no pixel lists)
-        torch.cuda.synchronize()
-        got = (img.detach().clone(), img2.clone(), cams.R.clone(), cams.T.clone(), [g.clone() for g in grads])
-        if ref is None:
-            ref = got
-            assert float(img.min()) < 0.9 and torch.isfinite(img).all()
-            continue
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), "images differ with %d pieces" % pieces
-        assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
-        for g, w in zip(got[4], ref[4]):
-            assert torch.equal(g, w), "gradients differ with %d pieces" % pieces
-    assert torch.equal(ref[0], ref[1])
-
-
-def test_forward_pieces_fragments_and_remedy(pieces_reset):
-    """pixel -> face maps with pieces, and the device-side rotation remedy (a degenerate view in the LAST piece makes every
-    piece re-draw all views: the verdict is global) — identical to one piece."""
-    F = pieces_reset
-    from mvtn_amd import MVRenderer, Meshes, PackedMeshes
-    dev = _dev()
-    vl, fl = zip(*[syn.synthetic_mesh("S", k) for k in range(6)])
-    B, V, size = 6, 4, 64
-    packed = PackedMeshes.from_meshes(Meshes(list(vl), list(fl)), dev)
-    az, el, di = _views(B, V, 11)
-    R, T, _ = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)), return_status=True)
-    params = F.mesh_params(V, size, 1, (1.0, 1.0, 1.0), (1.0, 1.0, 1.0))
-    light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
-    want = None
-    for pieces in (1, 2, 3):
-        F.set_forward_pieces(pieces)
-        img, p2f = F.render_meshes_fragments(packed, R, T, light, params)
-        torch.cuda.synchronize()
-        if want is None:
-            want = (img.clone(), p2f.clone())
-            assert int((p2f >= 0).sum()) > 1000
-        else:
-            assert torch.equal(p2f, want[1]) and torch.equal(img, want[0])
-    el_bad = el.copy()
-    el_bad[5, 3] = 90.0      # invalid rotation matrix -> remedy re-draws ALL views
-    outs = []
-    for pieces in (1, 3):
-        F.set_forward_pieces(pieces)
-        torch.manual_seed(5)     # the remedy's counter-based draws are keyed by (torch.initial_seed(), calls of this module)
-        r = MVRenderer(V, size, pc_rendering=False, rotation_check="device").eval()
-        with torch.no_grad():
-            img, cams = r(packed, None, _t(az), _t(el_bad), _t(di))
-        r.check_status()
-        torch.cuda.synchronize()
-        outs.append((img.clone(), cams.R.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    R_plain, _, _ = F.look_at_view_transform(_t(di.reshape(-1)), _t(el_bad.reshape(-1)), _t(az.reshape(-1)), return_status=True)
-    assert not torch.equal(outs[0][1][0], R_plain[0]), "the remedy re-draws every view, also those of the first piece"
-    assert torch.isfinite(outs[0][0]).all()
-
-
-def test_forward_pieces_inside_a_hip_graph(pieces_reset):
-    """The side stream forks from and joins the capturing stream through events: a training step with a 2-piece forward
-    captures into a HIP graph and replays bit-identically to eager execution."""
-    F = pieces_reset
-    from mvtn_amd import MVRenderer, Meshes, PackedMeshes
-    dev = _dev()
-    vl, fl = zip(*[syn.synthetic_mesh("M", k) for k in range(4)])
-    B, V, size = 4, 6, 96
-    packed = PackedMeshes.from_meshes(Meshes(list(vl), list(fl)), dev)
-    r = MVRenderer(V, size, pc_rendering=False, light_direction="relative").eval()
-    G = torch.randn(B, V, 3, size, size, generator=torch.Generator().manual_seed(4)).to(dev)
-    sets = [tuple(_t(x) for x in _views(B, V, seed)) for seed in (1, 2, 3)]
-    F.set_forward_pieces(2)
-
-    def step(a, e, d):
-        img, _ = r(packed, None, a, e, d)
-        return img, torch.autograd.grad((img * G).sum(), (a, e, d))
-
-    eager = []
-    for a, e, d in sets:
-        out, grads = step(*[x.clone().requires_grad_(True) for x in (a, e, d)])
-        eager.append((out.detach().clone(), [g.clone() for g in grads]))
-    sa, se, sd = (x.clone().requires_grad_(True) for x in sets[0])
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            step(sa, se, sd)
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        g_out, g_grads = step(sa, se, sd)
-    for (a, e, d), (want_out, want_grads) in zip(sets, eager):
-        with torch.no_grad():
-            sa.copy_(a); se.copy_(e); sd.copy_(d)
-        graph.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(g_out, want_out)
-        for got, want in zip(g_grads, want_grads):
-            assert torch.equal(got, want)
 
 
 def _write_off(path, v, f, glued=False):
