@@ -69,7 +69,9 @@ def test_mesh_files_through_the_renderer_against_the_oracle(oracle, tmp_path, fm
     lv, lf = mesh.verts_list()[0], mesh.faces_list()[0]
     assert lf.dtype == torch.int64 and np.array_equal(lf.numpy(), f)
     # the reference's chain on the written values (%.9g round-trips a float32): rotate (float64), to float32, centre, normalise
-    vv = io.rotation_matrix((1, 0, 0), -90.0).dot(v.astype(np.float64).T).T
+    v_text = np.array([[float("%.9g" % x) for x in p_] for p_ in v], np.float64)     # what a text parser reads back
+    assert np.array_equal(v_text.astype(np.float32), v)
+    vv = io.rotation_matrix((1, 0, 0), -90.0).dot(v_text.T).T
     want_v = io.torch_center_and_normalize(torch.from_numpy(vv).to(torch.float), p=2)
     assert torch.equal(lv, want_v)
     assert abs(float(torch.linalg.norm(lv, dim=1).max()) - 1.0) < 1e-6 and float(lv.mean(0).abs().max()) < 1e-6
