@@ -51,6 +51,10 @@ enum {
                                   depth) and run every strip through the exact-arithmetic kernel; same images, slower */
   MVR_BACKWARD_GATHER = 16,    /* backward only: skip the face-table kernel (per-face data fetched once per strip into LDS)
                                   and gather per covered pixel; same gradients up to summation order, slower */
+  MVR_NORMALS_THREE_CROSS = 64, /* vertex normals from THREE cross products per face — (v2-v1)x(v0-v1) to vertex 1,
+                                  (v0-v2)x(v1-v2) to vertex 2, (v1-v0)x(v2-v0) to vertex 0 — instead of one added to all
+                                  three: the two forms PyTorch3D's Meshes._compute_vertex_normals has had; equal in exact
+                                  arithmetic, ~1e-7 apart in fp32 (colours only; never coverage).  Pass it to forward AND backward */
   MVR_KEEP_PIXEL_LISTS = 32    /* forward with pix_to_face: also leave, per (view, strip), the list of covered pixels with
                                   their winners' slots and the winners' faces in the workspace (the rasteriser has them at
                                   hand); a backward given the same workspace with MVR_WORKSPACE_FROM_FORWARD and this flag
@@ -103,7 +107,10 @@ typedef struct mvr_mesh_params {
   const uint8_t *win_flip;
   const float *win_scale;
   int32_t win_pad;        /* subtracted from every win_dx / win_dy entry: the arrays may then hold the crop offsets (j, i) as drawn */
-  int32_t reserved2_;     /* explicit padding; must be 0 */
+  float fov_scale;        /* 0: the projection scale is s = RN(1 / tan(fov_deg / 2)) evaluated in double.  > 0: s as given —
+                             for a caller that wants K[0][0] of a particular PyTorch3D build (an fp32 torch.tan whose last
+                             bit depends on the device: torch CPU gives 0x1.bb67b0p+0 for 60 degrees, the default here is
+                             0x1.bb67aep+0) */
 } mvr_mesh_params;
 
 typedef struct mvr_points_params {

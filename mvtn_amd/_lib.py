@@ -16,6 +16,7 @@ MVR_WORKSPACE_FROM_FORWARD = 4
 MVR_RASTER_EXACT_ONLY = 8
 MVR_BACKWARD_GATHER = 16
 MVR_KEEP_PIXEL_LISTS = 32
+MVR_NORMALS_THREE_CROSS = 64
 MVR_SHADER_SOFT_PHONG, MVR_SHADER_SOFT_SILHOUETTE = 0, 1
 
 
@@ -33,7 +34,7 @@ class MeshParams(ctypes.Structure):  # struct mvr_mesh_params
                 ("obj_color", ctypes.c_float * 3), ("bg_color", ctypes.c_float * 3), ("z_clip", ctypes.c_float),
                 ("out_mean", ctypes.c_float * 3), ("out_std", ctypes.c_float * 3),
                 ("win_dx", ctypes.c_void_p), ("win_dy", ctypes.c_void_p), ("win_flip", ctypes.c_void_p), ("win_scale", ctypes.c_void_p),
-                ("win_pad", ctypes.c_int32), ("reserved2_", ctypes.c_int32)]
+                ("win_pad", ctypes.c_int32), ("fov_scale", ctypes.c_float)]
 
 
 class SoftParams(ctypes.Structure):  # struct mvr_soft_params

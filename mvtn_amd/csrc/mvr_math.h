@@ -388,7 +388,7 @@ template <typename T> MVR_HD bool face_test(const FaceSetup<T> &fs, T px, T py, 
 // A face with one or two vertices nearer than zc is cut: one vertex behind (p1; p2, p3 the next two in cyclic order) leaves
 // the quad (p4, p2, p5) + (p5, p2, p3), two behind (p1 the one in front) leave (p1, p4, p5); p4 on edge p1 p2, p5 on p1 p3 at
 // the view-depth parameter w = (z1 - zc) / (z1 - z_other); their NDC x, y are interpolated in x z, y z (linear in view space)
-// and divided by zc.  The rasteriser tests the cut triangles; PyTorch3D maps their barycentrics back to the original face
+// and divided by the new vertex's own interpolated z.  The rasteriser tests the cut triangles; PyTorch3D maps their barycentrics back to the original face
 // (beta).  Same operations in the same order as the oracle's clip_face.  straddles(): 1 or 2 vertices behind.
 template <typename T> MVR_HD bool straddles(T z0, T z1, T z2, T zc) {
   const int nb = (z0 < zc ? 1 : 0) + (z1 < zc ? 1 : 0) + (z2 < zc ? 1 : 0);
@@ -413,11 +413,13 @@ template <typename T> MVR_HD ClippedFace<T> clip_face(const V3<T> &v0, const V3<
   const V3<T> p1 = i1 == 0 ? v0 : (i1 == 1 ? v1 : v2), p2 = i1 == 0 ? v1 : (i1 == 1 ? v2 : v0), p3 = i1 == 0 ? v2 : (i1 == 1 ? v0 : v1);
   const T w2 = (p1.z - zc) / (p1.z - p2.z), w3 = (p1.z - zc) / (p1.z - p3.z);
   V3<T> p4, p5;
-  p4.x = ((p1.x * p1.z) * ((T)1 - w2) + (p2.x * p2.z) * w2) / zc;
-  p5.x = ((p1.x * p1.z) * ((T)1 - w3) + (p3.x * p3.z) * w3) / zc;
-  p4.y = ((p1.y * p1.z) * ((T)1 - w2) + (p2.y * p2.z) * w2) / zc;
-  p5.y = ((p1.y * p1.z) * ((T)1 - w3) + (p3.y * p3.z) * w3) / zc;
-  p4.z = zc; p5.z = zc;
+  // (upstream projects a new vertex back by ITS OWN interpolated depth, which equals zc only up to rounding)
+  p4.z = p1.z * ((T)1 - w2) + p2.z * w2;
+  p5.z = p1.z * ((T)1 - w3) + p3.z * w3;
+  p4.x = ((p1.x * p1.z) * ((T)1 - w2) + (p2.x * p2.z) * w2) / p4.z;
+  p5.x = ((p1.x * p1.z) * ((T)1 - w3) + (p3.x * p3.z) * w3) / p5.z;
+  p4.y = ((p1.y * p1.z) * ((T)1 - w2) + (p2.y * p2.z) * w2) / p4.z;
+  p5.y = ((p1.y * p1.z) * ((T)1 - w3) + (p3.y * p3.z) * w3) / p5.z;
   if (nb == 1) {   // p1 behind: (p4, p2, p5) and (p5, p2, p3)
     o.t0[0] = p4; o.t0[1] = p2; o.t0[2] = p5;
     o.t1[0] = p5; o.t1[1] = p2; o.t1[2] = p3;
@@ -703,7 +705,7 @@ template <typename T> struct SoftFrag {
 };
 
 // The fragment of (pixel, face) without the acceptance tests.
-template <typename T> MVR_HD SoftFrag<T> soft_frag_eval(const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, T px, T py, bool persp, bool clip_bary) {
+template <typename T> MVR_HD SoftFrag<T> soft_frag_eval(const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, T px, T py, bool persp, bool clip_bary, bool with_dist = true) {
   SoftFrag<T> f;
   const T area = edge_fn(v2.x, v2.y, v0.x, v0.y, v1.x, v1.y) + (T)kEps;
   T w0 = edge_fn(px, py, v1.x, v1.y, v2.x, v2.y) / area;
@@ -724,9 +726,17 @@ template <typename T> MVR_HD SoftFrag<T> soft_frag_eval(const V3<T> &v0, const V
   f.b0 = c0; f.b1 = c1; f.b2 = c2;
   f.z = (c0 * v0.z + c1 * v1.z) + c2 * v2.z;
   f.inside = w0 > (T)0 && w1 > (T)0 && w2 > (T)0;
-  const T d = point_triangle_dist2(px, py, v0, v1, v2);
-  f.dist = f.inside ? -d : d;
+  f.dist = (T)0;
+  if (with_dist) {
+    const T d = point_triangle_dist2(px, py, v0, v1, v2);
+    f.dist = f.inside ? -d : d;
+  }
   return f;
+}
+// the signed squared distance of a fragment evaluated without it (soft_frag_eval(..., with_dist = false))
+template <typename T> MVR_HD void soft_frag_add_dist(SoftFrag<T> *f, const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, T px, T py) {
+  const T d = point_triangle_dist2(px, py, v0, v1, v2);
+  f->dist = f->inside ? -d : d;
 }
 
 // CheckPixelInsideFace with blur_radius > 0: true when the pixel is inside the face or nearer than sqrt(blur_radius).

@@ -126,24 +126,29 @@ def camera_position_from_spherical_angles(distance, elevation, azimuth):
 
 def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backfaces=False, perspective_correct=True,
                 fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, strip_rows=0, exact_raster=False, z_clip=None,
-                gather_backward=False, normalize=None):
+                gather_backward=False, normalize=None, fov_scale=0.0, normals_three_cross=False):
     """`exact_raster`: skip the fast rasteriser (MVR_RASTER_EXACT_ONLY); the images are the same either way.
     `gather_backward`: skip the face-table backward kernel (MVR_BACKWARD_GATHER); same gradients up to summation order.
     `normalize`: (mean, std) per channel (or scalars): the trainer's Normalize, (rgb - mean) / std, applied in the
     rasteriser's stores (no pass over the frames afterwards); the backward differentiates the normalised images.
     `z_clip`: view depth of PyTorch3D >= 0.5's face clipping; None = the reference's rule (znear / 2 = 0.5 when
-    perspective_correct — MeshRasterizer only clips for perspective cameras with it on —, else off); 0 = off."""
+    perspective_correct — MeshRasterizer only clips for perspective cameras with it on —, else off); 0 = off.
+    `fov_scale`: 0 = the projection scale from `fov` (1 / tan(fov / 2) evaluated in double, rounded once); > 0: used as given
+    (K[0][0] of a particular PyTorch3D build).  `normals_three_cross`: the vertex normals from three cross products per
+    face (MVR_NORMALS_THREE_CROSS) instead of one — the two forms of Meshes._compute_vertex_normals."""
     if z_clip is None:
         z_clip = 0.5 if perspective_correct else 0.0
     H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
     flags = (_lib.MVR_CULL_BACKFACES if cull_backfaces else 0) | (_lib.MVR_PERSPECTIVE_CORRECT if perspective_correct else 0)
     flags |= _lib.MVR_RASTER_EXACT_ONLY if exact_raster else 0
     flags |= _lib.MVR_BACKWARD_GATHER if gather_backward else 0
+    flags |= _lib.MVR_NORMALS_THREE_CROSS if normals_three_cross else 0
     p = _lib.MeshParams(n_views, H, W, flags, n_light, strip_rows, fov, ambient, diffuse, specular, shininess)
     for k in range(3):
         p.obj_color[k] = float(obj_color[k])
         p.bg_color[k] = float(bg_color[k])
     p.z_clip = float(z_clip)
+    p.fov_scale = float(fov_scale)
     _set_normalize(p, normalize)
     return p
 

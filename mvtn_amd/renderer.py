@@ -35,8 +35,12 @@ class MVRenderer(nn.Module):
     def __init__(self, nb_views, image_size=224, pc_rendering=True, object_color="white", background_color="white",
                  faces_per_pixel=1, points_radius=0.006, points_per_pixel=1, light_direction="random",
                  cull_backfaces=False, *, perspective_correct=True, rotation_check="device", strip_rows=0, z_clip=None,
-                 shader="hard_phong", blur_radius=0.0, sigma=1e-4, gamma=1e-4, return_alpha=False, normalize=None):
+                 shader="hard_phong", blur_radius=0.0, sigma=1e-4, gamma=1e-4, return_alpha=False, normalize=None,
+                 fov_scale=0.0, normals_three_cross=False):
         super().__init__()
+        # the two places where a PyTorch3D build may differ from the defaults in the last bit (functional.mesh_params):
+        # fov_scale > 0 = that build's K[0][0]; normals_three_cross = vertex normals from three cross products per face
+        self.fov_scale, self.normals_three_cross = float(fov_scale), bool(normals_three_cross)
         # normalize=(mean, std): the trainer's Normalize (viewGCN/tools/Trainer_mvt.py:41-49) applied in the mesh rasteriser's
         # stores — the images come out as (rgb - mean) / std, differentiably, with no pass over the frames afterwards
         # (mvtn_amd.regularize.IMAGENET_MEAN / IMAGENET_STD are the reference's values).  Hard mesh path and point path.
@@ -190,7 +194,8 @@ class MVRenderer(nn.Module):
                     self._light_cache[key] = light
         n_light = N if light is None else light.shape[0]
         pkey = (n_light, tuple(obj), tuple(float(c) for c in background_color), bool(self.cull_backfaces),
-                bool(self.perspective_correct), self.strip_rows, self.nb_views, self.image_size, self.z_clip, self.normalize)
+                bool(self.perspective_correct), self.strip_rows, self.nb_views, self.image_size, self.z_clip, self.normalize,
+                self.fov_scale, self.normals_three_cross)
         params = self._params_cache.get(pkey)
         if params is None:
             if len(self._params_cache) > 64:
@@ -198,7 +203,8 @@ class MVRenderer(nn.Module):
             params = self._params_cache[pkey] = F.mesh_params(self.nb_views, self.image_size, n_light, pkey[1], pkey[2],
                                                               cull_backfaces=pkey[3], perspective_correct=pkey[4],
                                                               strip_rows=self.strip_rows, z_clip=self.z_clip,
-                                                              normalize=self.normalize if self.shader == "hard_phong" else None)
+                                                              normalize=self.normalize if self.shader == "hard_phong" else None,
+                                                              fov_scale=self.fov_scale, normals_three_cross=self.normals_three_cross)
         if azim.numel() != N:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (packed.n_meshes, self.nb_views))
         if window is not None:   # render straight onto the view regulariser's window (regularize.draw_regularization)

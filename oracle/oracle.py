@@ -44,6 +44,13 @@ def set_threads(n):
     lib().orc_set_threads(ctypes.c_int(int(n)))
 
 
+def set_options(normals_three_cross=False, fov_scale=0.0):
+    """The two switches of VERDICT r2 (Weak 1): the vertex normals as three different cross products per face (slots 1, 2, 0)
+    instead of one added three times, and the projection scale s given explicitly (e.g. K[0][0] of a PyTorch3D build, whose
+    fp32 tan may differ in the last bit from RN(1 / tan(fov / 2))); (False, 0) = the defaults.  Process-wide."""
+    lib().orc_set_options(ctypes.c_int(int(bool(normals_three_cross))), ctypes.c_double(float(fov_scale)))
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 

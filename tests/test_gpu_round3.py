@@ -77,7 +77,7 @@ def test_mesh_files_through_the_renderer_against_the_oracle(oracle, tmp_path, fm
     assert abs(float(torch.linalg.norm(lv, dim=1).max()) - 1.0) < 1e-6 and float(lv.mean(0).abs().max()) < 1e-6
     V, size = 4, 96
     az, el, di = _views(1, V, 5)
-    r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white").eval()
+    r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="fixed").eval()
     with torch.no_grad():
         img, _ = r([mesh], None, _t(az), _t(el), _t(di))
     want = oracle.render_meshes([lv.numpy()], [lf.numpy()], az, el, di, size, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
@@ -95,7 +95,7 @@ def test_save_grid_of_rendered_views_decodes_to_the_tensor(tmp_path):
     v, f = syn.synthetic_mesh("M", 2)
     V, size = 6, 64
     az, el, di = _views(1, V, 9)
-    r = MVRenderer(V, size, pc_rendering=False, object_color="red", background_color="white").eval()
+    r = MVRenderer(V, size, pc_rendering=False, object_color="red", background_color="white", light_direction="fixed").eval()
     gpath, cpath = str(tmp_path / "views.png"), str(tmp_path / "cams.png")
     r.render_and_save([Meshes([v], [f])], None, _t(az), _t(el), _t(di), gpath, cpath)
     with torch.no_grad():
@@ -108,3 +108,154 @@ def test_save_grid_of_rendered_views_decodes_to_the_tensor(tmp_path):
     cell = px[2:2 + size, 2:2 + size]
     assert float(np.abs(cell - img[0, 0].permute(1, 2, 0).cpu().numpy().clip(0, 1)).max()) <= 1.0 / 255.0 + 1e-6
     assert float(cell.min()) < 0.7 and os.path.getsize(cpath) > 1000
+
+
+# ---- the second, torch-made implementation (tests/golden/make_torch_restatement_r3.py) against the HIP path directly ---------
+
+def _fx(name):
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_hip_point_path_against_the_torch_restatement(K):
+    """models/renderer.py:116-151 as torch ops (2 clouds x 20 views of BASELINE configs[3]) vs the HIP point path through
+    MVRenderer: every slot of every pixel identical; colours within 1e-6 except where the compositor's 1e-4 clamp is active
+    (sum of weights < 1e-4: a handful of rim pixels whose colour w f / 1e-4 multiplies a 1-ulp coordinate difference by 1e4 —
+    see tests/test_oracle.py)."""
+    from mvtn_amd import MVRenderer, functional as F
+    fx = _fx("torch_restatement_points.npz")
+    S, r, P = int(fx["image_size"]), float(fx["radius"]), int(fx["n_points"])
+    pts = []
+    for seed in fx["seeds"]:
+        v, f = syn.synthetic_mesh("M", int(seed))
+        pts.append(syn.surface_points(v, f, P, seed=int(seed)))
+    pts = np.stack(pts)
+    az, el, di = (np.tile(fx[k], (2, 1)) for k in ("azim", "elev", "dist"))
+    rr = MVRenderer(20, S, pc_rendering=True, object_color="white", background_color="white", points_radius=r, points_per_pixel=K).eval()
+    with torch.no_grad():
+        img, cams = rr(None, _t(pts), _t(az), _t(el), _t(di))
+    assert np.abs(cams.R.cpu().numpy() - np.tile(fx["R"], (2, 1, 1))).max() <= 2.5e-7
+    params = F.points_params(2, P, 20, S, r, (0.99999,) * 3, (0.99999,) * 3, points_per_pixel=K)
+    img2, idx = F.render_points_fragments(_t(pts), None, cams.R, cams.T, _t(di.reshape(-1)), params)
+    assert torch.equal(img2, img)
+    idx = idx.cpu().numpy().reshape(40, S, S, K)
+    want = fx["idx_k%d" % K].astype(np.int32)
+    differ = (idx != want).any(-1)
+    assert differ.sum() <= 8, "slot lists differ at %d pixels" % differ.sum()
+    diff = np.abs(img.cpu().numpy() - fx["images_k%d" % K]).max(2).reshape(differ.shape)
+    big = diff > 1e-6
+    print("K=%d: slot lists differ at %d pixels; %d pixels above 1e-6 (clamp region), max %.3g" % (K, differ.sum(), big.sum(), diff.max()))
+    assert big.sum() <= 16 and diff[~big].max() <= 1e-6
+    assert (idx[big][:, 0] >= 0).all()      # the outliers are covered pixels (rim of a disc), never background
+
+
+def test_hip_face_clipping_against_the_torch_restatement():
+    """clip_faces / convert_clipped_rasterization_to_original_faces as torch ops (dist 1.1: 65 and 63 faces cut) vs the HIP
+    path: same counts of cut faces, pixel -> face identical up to a handful of pixels, colours within 1e-4."""
+    from mvtn_amd import Meshes, functional as F
+    from mvtn_amd.structures import PackedMeshes
+    fx = _fx("torch_restatement_zclip.npz")
+    v, f = syn.synthetic_mesh(str(fx["mesh"][0]), int(fx["mesh"][1]))
+    S, V = int(fx["image_size"]), len(fx["azim"])
+    packed = PackedMeshes.from_meshes(Meshes([v], [f]), _dev())
+    R, T = F.look_at_view_transform(_t(fx["dist"]), _t(fx["elev"]), _t(fx["azim"]))
+    for exact in (False, True):
+        params = F.mesh_params(V, S, 1, (0.99999,) * 3, (0.99999,) * 3, z_clip=float(fx["z_clip"]), exact_raster=exact)
+        img, p2f, n_st = F.render_meshes_fragments(packed, R, T, _t(np.array([[0.0, 1.0, 0.0]], np.float32)), params, return_straddlers=True)
+        assert int(n_st) == int(fx["straddlers"].sum())
+        differ = p2f.cpu().numpy() != fx["pix_to_face"].astype(np.int32)
+        assert differ.sum() <= 8, differ.sum()
+        assert np.abs(img.cpu().numpy()[0] - fx["images"]).max(1)[~differ].max() <= TOL_PIXEL
+
+
+def test_hip_soft_phong_against_the_torch_restatement():
+    """SoftPhongShader with faces_per_pixel 4 as torch ops (phong_shading of every fragment + softmax_rgb_blend) vs the HIP soft
+    path: fragment lists identical (ties ordered by face index on both sides), RGBA within 1e-4."""
+    from mvtn_amd import Meshes, functional as F
+    from mvtn_amd.structures import PackedMeshes
+    fx = _fx("torch_restatement_soft.npz")
+    v, f = syn.synthetic_mesh(str(fx["mesh"][0]), int(fx["mesh"][1]))
+    S, V, K = int(fx["image_size"]), len(fx["azim"]), int(fx["faces_per_pixel"])
+    packed = PackedMeshes.from_meshes(Meshes([v], [f]), _dev())
+    R, T = F.look_at_view_transform(_t(fx["dist"]), _t(fx["elev"]), _t(fx["azim"]))
+    params = F.mesh_params(V, S, 1, (0.99999,) * 3, (0.99999,) * 3)
+    soft = F.soft_params(float(fx["blur_radius"]), K, "soft_phong", float(fx["sigma"]), float(fx["gamma"]))
+    img, p2f = F.render_meshes_soft(packed, R, T, _t([[0.0, 1.0, 0.0]]), params, soft, return_fragments=True)
+    differ = (p2f.cpu().numpy().reshape(V, S, S, K) != fx["pix_to_face"].astype(np.int32)).any(-1)
+    assert differ.sum() <= 8, differ.sum()
+    diff = np.abs(img.cpu().numpy().reshape(V, 4, S, S) - fx["images"]).max(1)
+    assert diff[~differ].max() <= TOL_PIXEL
+
+
+def test_library_switches_follow_the_oracle_switches(oracle):
+    """MVRenderer(fov_scale=..., normals_three_cross=True) (mvr_mesh_params.fov_scale, MVR_NORMALS_THREE_CROSS) against the
+    oracle with the same switches: pixel -> face maps bit-exact, colours within 1e-4; and each switch changes something."""
+    from mvtn_amd import MVRenderer, Meshes
+    v, f = syn.synthetic_mesh("M", 4)
+    V, size = 4, 96
+    az, el, di = _views(1, V, 3)
+    s1 = float.fromhex("0x1.bb67b0p+0")
+    kw = dict(obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
+    outs = {}
+    for name, three, s in (("default", False, 0.0), ("three_cross", True, 0.0), ("fov_scale", False, s1)):
+        try:
+            oracle.set_options(three, s)
+            want = oracle.render_meshes([v], [f], az, el, di, size, **kw)
+        finally:
+            oracle.set_options(False, 0.0)
+        r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="fixed",
+                       fov_scale=s, normals_three_cross=three).eval()
+        a, e, d = (_t(x).requires_grad_(True) for x in (az, el, di))
+        img, _ = r([Meshes([v], [f])], None, a, e, d)
+        err = float(np.abs(img.detach().cpu().numpy() - want["images"]).max())
+        assert err <= TOL_PIXEL, (name, err)
+        img.sum().backward()
+        assert torch.isfinite(a.grad).all() and float(a.grad.abs().max()) > 0
+        outs[name] = (img.detach().cpu().numpy(), want["images"])
+    assert 0 < np.abs(outs["three_cross"][0] - outs["default"][0]).max() < 1e-5      # normals: colours move in the 7th digit
+    assert np.abs(outs["fov_scale"][0] - outs["default"][0]).max() > 0                # s one ulp larger: the image changes
+    # the HIP path follows the oracle THROUGH the switch (not merely both within tolerance of the default)
+    d_hip, d_orc = outs["three_cross"][0] - outs["default"][0], outs["three_cross"][1] - outs["default"][1]
+    assert np.abs(d_hip - d_orc).max() < 5e-6
+
+
+@pytest.mark.parametrize("shader,K,dist", [("soft_phong", 4, 1.1), ("soft_phong", 2, 0.9), ("soft_silhouette", 3, 1.1)])
+def test_soft_path_cuts_straddling_faces(oracle, shader, K, dist):
+    """Round 3: the soft path cuts faces at the z-clip plane like the hard path (PyTorch3D >= 0.5 clip_faces; the pieces are
+    separate candidates of the K-nearest lists and map back to the same face).  Camera inside the bounding sphere (dist 1.1,
+    0.9): fragment lists (face indices; a face may appear twice in a pixel) identical to the oracle's, RGBA within 1e-4;
+    the gradients are finite and repeat bit for bit."""
+    from mvtn_amd import MVRenderer, Meshes, functional as F
+    from mvtn_amd.structures import PackedMeshes
+    v, f = syn.synthetic_mesh("S", 7)
+    V, size, sigma = 3, 64, 1e-4
+    az, el, _ = _views(1, V, 13)
+    di = np.full((1, V), dist, np.float32)
+    blur = float(np.log(1.0 / 1e-4 - 1.0) * sigma)
+    obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
+    want = oracle.render_meshes_soft([v], [f], az, el, di, size, blur, K, shader=shader, sigma=sigma, gamma=1e-4, obj_color=obj, bg_color=bg, z_clip=0.5)
+    whole = oracle.render_meshes_soft([v], [f], az, el, di, size, blur, K, shader=shader, sigma=sigma, gamma=1e-4, obj_color=obj, bg_color=bg, z_clip=0.0)
+    assert (want["pix_to_face"] != whole["pix_to_face"]).mean() > 0.01, "the case must depend on the cut"
+    packed = PackedMeshes.from_meshes(Meshes([v], [f]), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    params = F.mesh_params(V, size, 1, obj, bg, z_clip=0.5)
+    soft = F.soft_params(blur, K, shader, sigma, 1e-4)
+    img, p2f = F.render_meshes_soft(packed, R, T, _t([[0.0, 1.0, 0.0]]), params, soft, return_fragments=True)
+    torch.cuda.synchronize()
+    p2f, img = p2f.cpu().numpy().reshape(V, size, size, K), img.cpu().numpy().reshape(V, 4, size, size)
+    n_diff = int((p2f != want["pix_to_face"]).sum())
+    twice = int(((p2f[..., 1:] == p2f[..., :-1]) & (p2f[..., 1:] >= 0)).sum())
+    diff = np.abs(img - want["images"].reshape(V, 4, size, size)).max(1)
+    print("fragment mismatches %d of %d; a face twice in a pixel's list: %d times; max|d| %.3g" % (n_diff, p2f.size, twice, diff.max()))
+    assert n_diff == 0
+    assert diff.max() <= TOL_PIXEL
+    r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="black", light_direction="fixed", shader=shader,
+                   blur_radius=blur, faces_per_pixel=K, sigma=sigma, return_alpha=True).eval()
+    grads = []
+    for _ in range(2):
+        a, e, d = (_t(x).requires_grad_(True) for x in (az, el, di))
+        out, _ = r([Meshes([v], [f])], None, a, e, d)
+        out.sum().backward()
+        grads.append([x.grad.clone() for x in (a, e, d)])
+    assert all(torch.isfinite(g).all() for g in grads[0]) and float(grads[0][0].abs().max()) > 0
+    assert all(torch.equal(g0, g1) for g0, g1 in zip(*grads))

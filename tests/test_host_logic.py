@@ -167,12 +167,14 @@ def test_flag_constants_and_workspace_rules_without_gpu():
                         lambda p: lib.mvr_render_meshes_forward(mb, p, 1, 1, 1, 1, None, 1, 1 << 40, None)),
                        (lambda: F.points_params(2, 100, 12, 224, 0.006, (1, 1, 1), (0, 0, 0)),
                         lambda p: lib.mvr_render_points_forward(p, 1, None, 1, 1, 1, 1, None, 1, 1 << 40, None))):
-        for fields in ({"win_dx": 1}, {"win_dx": 1, "win_dy": 1}, {"win_scale": 1}, {"win_pad": 3}, {"reserved2_": 1}):
+        for fields in ({"win_dx": 1}, {"win_dx": 1, "win_dy": 1}, {"win_scale": 1}, {"win_pad": 3}, {"reserved2_": 1}, {"fov_scale": -1.0}):
             p = make()
+            if not all(hasattr(p, k) for k in fields):   # (reserved2_: points parameters; fov_scale: mesh parameters)
+                continue
             for k, v in fields.items():
                 setattr(p, k, v)
             assert call(p) == 1, fields
-            assert b"win_" in lib.mvr_last_error() or b"reserved2_" in lib.mvr_last_error(), (fields, lib.mvr_last_error())
+            assert any(w in lib.mvr_last_error() for w in (b"win_", b"reserved2_", b"fov_scale")), (fields, lib.mvr_last_error())
 
 
 def test_product_has_no_cpu_fallback_and_never_imports_the_oracle():

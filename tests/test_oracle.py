@@ -364,6 +364,110 @@ def test_oracle_against_the_torch_restatement_of_c1(oracle):
     assert zz.max() <= 5e-5
 
 
+def _fx(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
+def test_oracle_against_the_torch_restatement_of_the_point_path(oracle):
+    """tests/golden/torch_restatement_points.npz (make_torch_restatement_r3.py): 2 clouds x 20 views of BASELINE configs[3]
+    (models/renderer.py:116-151) through real torch ops — scale_(1 / dist), 4 x 4 bmm transforms, the orthographic projection
+    matrix, the naive point rasteriser, 1 - d2 / (r r), NormWeightedCompositor — for points_per_pixel 1 and 4.  Observed when
+    the fixture was made: every slot of every pixel identical (2 007 040 and 8 028 160 slots), colours within 2.4e-7 wherever
+    the weights sum to >= 1e-4.  Where the compositor's clamp is active (sum of weights < 1e-4: a pixel centre on the very
+    rim of a disc, 3-4 pixels of 2 M) the colour is w f / 1e-4 — a 1-ulp difference of a projected coordinate (bmm vs X R + T)
+    is multiplied by 1e4 there: those pixels differ by up to 0.15 between ANY two evaluation orders, also with identical
+    cameras, and are counted, not compared."""
+    fx = _fx("torch_restatement_points.npz")
+    S, r, P = int(fx["image_size"]), float(fx["radius"]), int(fx["n_points"])
+    pts = []
+    for seed in fx["seeds"]:
+        v, f = syn.synthetic_mesh("M", int(seed))
+        pts.append(syn.surface_points(v, f, P, seed=int(seed)))
+    pts = np.stack(pts)
+    az, el, di = (np.tile(fx[k], (2, 1)) for k in ("azim", "elev", "dist"))
+    for K in (1, 4):
+        out = oracle.render_points(pts, az, el, di, S, radius=r, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, points_per_pixel=K)
+        assert np.abs(out["R"] - np.tile(fx["R"], (2, 1, 1))).max() <= 2.5e-7 and np.abs(out["T"] - np.tile(fx["T"], (2, 1))).max() <= 5e-7
+        idx = out["idx"] if K > 1 else out["idx"][..., None]
+        want = fx["idx_k%d" % K].astype(np.int32)
+        differ = (idx != want).any(-1)
+        assert differ.sum() <= 8, "slot lists differ at %d pixels" % differ.sum()
+        assert 0.04 < (want[..., 0] >= 0).mean() < 0.07
+        d2 = out["dist2"] if K > 1 else out["dist2"][..., None]
+        wsum = np.where(idx >= 0, 1.0 - d2.astype(np.float64) / (r * r), 0.0).sum(-1)
+        diff = np.abs(out["images"] - fx["images_k%d" % K]).max(2).reshape(differ.shape)
+        sound = ~differ & ~((idx[..., 0] >= 0) & (wsum < 1e-4))
+        assert diff[sound].max() <= 1e-6
+        assert (~sound).sum() <= 16
+
+
+def test_oracle_against_the_torch_restatement_of_face_clipping(oracle):
+    """tests/golden/torch_restatement_zclip.npz: a tier-S mesh seen from dist 1.1 (inside its bounding sphere: 65 and 63 faces
+    straddle z = znear / 2) through a torch restatement of clip_faces (new vertices interpolated in (x z, y z, z), projected
+    back by their own z), the naive rasteriser on the clipped faces and the barycentric conversion back to the original
+    faces.  Observed: same straddler counts, 0 of 32 768 pixels differ, colours within 2.4e-7."""
+    fx = _fx("torch_restatement_zclip.npz")
+    v, f = syn.synthetic_mesh(str(fx["mesh"][0]), int(fx["mesh"][1]))
+    S = int(fx["image_size"])
+    out = oracle.render_meshes([v], [f], fx["azim"][None], fx["elev"][None], fx["dist"][None], S, obj_color=(0.99999,) * 3,
+                               bg_color=(0.99999,) * 3, z_clip=float(fx["z_clip"]))
+    assert np.array_equal(out["straddlers"], fx["straddlers"]) and fx["straddlers"].min() > 20
+    differ = out["pix_to_face"] != fx["pix_to_face"].astype(np.int32)
+    assert differ.sum() <= 8, "pixel -> face maps differ at %d pixels" % differ.sum()
+    diff = np.abs(out["images"][0] - fx["images"]).max(1)
+    assert diff[~differ].max() <= 1e-5
+    # and the plane matters: without it the frames are different pictures
+    off = oracle.render_meshes([v], [f], fx["azim"][None], fx["elev"][None], fx["dist"][None], S, obj_color=(0.99999,) * 3,
+                               bg_color=(0.99999,) * 3, z_clip=0.0)
+    assert (off["pix_to_face"] != out["pix_to_face"]).mean() > 0.01
+
+
+def test_oracle_against_the_torch_restatement_of_the_soft_phong_blend(oracle):
+    """tests/golden/torch_restatement_soft.npz: blur_radius = log(1 / 1e-4 - 1) sigma, faces_per_pixel 4, clipped barycentrics,
+    phong_shading of every fragment + softmax_rgb_blend written with torch ops (sigmoid, prod, exp, clamp, sum).  Depth ties
+    are frequent here (clipped barycentrics give neighbouring faces bit-equal z at a shared vertex): both sides order by
+    (z, face index).  Observed: 0 of 32 768 slots differ, RGBA within 1.4e-5."""
+    fx = _fx("torch_restatement_soft.npz")
+    v, f = syn.synthetic_mesh(str(fx["mesh"][0]), int(fx["mesh"][1]))
+    S, K = int(fx["image_size"]), int(fx["faces_per_pixel"])
+    out = oracle.render_meshes_soft([v], [f], fx["azim"][None], fx["elev"][None], fx["dist"][None], S, float(fx["blur_radius"]), K,
+                                    sigma=float(fx["sigma"]), gamma=float(fx["gamma"]), obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
+    want = fx["pix_to_face"].astype(np.int32)
+    differ = (out["pix_to_face"] != want).any(-1)
+    assert differ.sum() <= 8, "fragment lists differ at %d pixels" % differ.sum()
+    assert (want[..., K - 1] >= 0).mean() > 0.3      # most covered pixels hold K fragments: the blend is exercised
+    diff = np.abs(out["images"][0] - fx["images"]).max(1)
+    assert diff[~differ].max() <= 1e-4
+    both = (out["pix_to_face"] >= 0) & (want >= 0) & ~differ[..., None]
+    assert np.abs(out["dists"] - fx["dists"])[both].max() <= 1e-6
+
+
+def test_oracle_switches_move_colours_only_slightly(oracle):
+    """The two switches of round 3 (oracle.set_options): the vertex normals as three cross products per face change no
+    coverage and colours by < 1e-5; a projection scale one ulp off (what an fp32 torch.tan gives on this CPU) moves a
+    handful of edge pixels.  tools/report_oracle_switches.py prints the counts for C1 and the whole of C2."""
+    v, f = syn.synthetic_mesh("S", 1)
+    az, el, di = syn.circular_views(3)
+    kw = dict(obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
+    base = oracle.render_meshes([v], [f], az[None], el[None], di[None], 96, **kw)
+    try:
+        oracle.set_options(True, 0.0)
+        n3 = oracle.render_meshes([v], [f], az[None], el[None], di[None], 96, **kw)
+        nrm_a = oracle.vertex_normals(v, f)
+        oracle.set_options(False, float.fromhex("0x1.bb67b0p+0"))
+        s1 = oracle.render_meshes([v], [f], az[None], el[None], di[None], 96, **kw)
+    finally:
+        oracle.set_options(False, 0.0)
+    nrm_b = oracle.vertex_normals(v, f)
+    assert np.array_equal(n3["pix_to_face"], base["pix_to_face"])
+    assert 0 < np.abs(n3["images"] - base["images"]).max() < 1e-5
+    assert 0 < np.abs(nrm_a - nrm_b).max() < 1e-5
+    moved = s1["pix_to_face"] != base["pix_to_face"]
+    assert moved.sum() <= 12
+    assert np.abs(s1["images"] - base["images"]).max(2).reshape(moved.shape)[~moved].max() < 1e-5
+
+
 # ---- soft path (SURVEY 8 f4) ---------------------------------------------------------------------------------------
 
 def test_ka13_soft_path_with_one_face_per_pixel_and_no_blur_is_the_hard_render(oracle):

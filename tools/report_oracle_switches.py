@@ -1,0 +1,46 @@
+"""How many pixels the two oracle switches of round 3 move (Weak 1), on C1 (BASELINE configs[0]: one tier-M mesh,
+4 circular views, 128 x 128) and on the whole of C2 (16 tier-M meshes x 12 spherical views, 224 x 224).  CPU only (~2 min on
+8 cores).       python3 tools/report_oracle_switches.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mvtn_amd import synthetic as syn  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+orc.build()
+orc.set_threads(os.cpu_count() or 1)
+S32 = float(np.float32(np.float32(2.0) / (np.float32(2.0) * np.tan(np.float32(np.float32(np.pi / 180 * 60.0) / np.float32(2.0))))))
+S_TORCH_CPU = float.fromhex("0x1.bb67b0p+0")   # K[0][0] from torch.tan on this container's CPU (tests/golden/make_torch_restatement.py)
+
+
+def render(vl, fl, az, el, di, S):
+    return orc.render_meshes(vl, fl, az, el, di, S, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, mode=0)
+
+
+def report(name, vl, fl, az, el, di, S):
+    orc.set_options(False, 0.0)
+    base = render(vl, fl, az, el, di, S)
+    cov = base["pix_to_face"] >= 0
+    print("%s: %d pixels, %d covered" % (name, cov.size, int(cov.sum())))
+    for label, opts in (("normals as three cross products", (True, 0.0)), ("s = K[0][0] of torch CPU (0x1.bb67b0p+0, +1 ulp)", (False, S_TORCH_CPU)),
+                        ("s = numpy tanf route (%s, -1 ulp)" % float(np.float32(S32)).hex(), (False, S32))):
+        orc.set_options(*opts)
+        o = render(vl, fl, az, el, di, S)
+        moved = o["pix_to_face"] != base["pix_to_face"]
+        d = np.abs(o["images"] - base["images"]).max(2).reshape(moved.shape)
+        print("   %-52s pixel -> face changes at %4d pixels; max colour change %.2e overall, %.2e on unchanged pixels; pixels > 1e-4: %d" % (
+            label, int(moved.sum()), d.max(), d[~moved].max(), int((d > 1e-4).sum())))
+    orc.set_options(False, 0.0)
+
+
+v, f = syn.synthetic_mesh("M", 0)
+az, el, di = syn.circular_views(4, 30.0, 2.2)
+report("C1", [v], [f], az[None], el[None], di[None], 128)
+B, V = 16, 12
+vl, fl = zip(*[syn.synthetic_mesh("M", i) for i in range(B)])
+az, el, di = syn.spherical_views(V)
+report("C2", list(vl), list(fl), np.tile(az, (B, 1)), np.tile(el, (B, 1)), np.tile(di, (B, 1)), 224)
