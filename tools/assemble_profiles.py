@@ -23,8 +23,12 @@ def pmc(dirn, kern):
     return vals
 
 
-for w in ("mesh_fwd", "mesh_fwdbwd", "points_fwd", "c5"):
-    f = glob.glob("%s/stats_%s/**/*kernel_stats.csv" % (src, w), recursive=True)[0]
+for w in ("mesh_fwd", "mesh_fwdbwd", "points_fwd", "c5_per_gpu", "c5", "soft_fwdbwd"):
+    fs = glob.glob("%s/stats_%s/**/*kernel_stats.csv" % (src, w), recursive=True)
+    if not fs:
+        print(w, "(no kernel stats)")
+        continue
+    f = fs[0]
     shutil.copy(f, "%s/%s_kernel_stats_%s.csv" % (dst, tag, w))
     shutil.copy("%s/bench_%s.json" % (src, w), "%s/%s_bench_%s.json" % (dst, tag, w))
     print(w)

@@ -1,11 +1,13 @@
 # Collects the round's judged measurements on the GPU box into gpurun_out/$1 (run from the repo root through gpurun):
 #   bench lines (un-profiled), rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE passes and SQ counter passes.
+#   (c5 = BASELINE configs[4] on one GPU: all 64 objects; c5_per_gpu = one GPU's share at N = 8, the `c5` of rounds 1-2)
 # Every profiler run is bounded by `timeout` (a counter combination that stalls must not eat the GPU budget).
 out=gpurun_out/${1:-prof}
 mkdir -p $out
 export TMPDIR=/tmp
-for w in mesh_fwd mesh_fwdbwd points_fwd c5; do
-  timeout 300 python3 bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err
+for w in mesh_fwd mesh_fwdbwd points_fwd c5_per_gpu c5 soft_fwdbwd; do
+  st=""; [ $w = soft_fwdbwd ] && st="--steps 100 --warmup 10 --cpu-views 4"; [ $w = c5 ] && st="--steps 200 --warmup 20"
+  timeout 400 python3 bench.py --workload $w $st > $out/bench_$w.json 2> $out/bench_$w.err
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$w -- python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-pipelined > /dev/null 2>&1
 done
 for w in mesh_fwd mesh_fwdbwd points_fwd; do
@@ -22,4 +24,4 @@ timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_
 find $out -name "*kernel_trace.csv" -delete
 find $out -name "*agent_info.csv" -delete
 du -sh $out
-for w in mesh_fwd mesh_fwdbwd points_fwd c5; do tail -1 $out/bench_$w.json | cut -c1-400; done
+for w in mesh_fwd mesh_fwdbwd points_fwd c5_per_gpu c5 soft_fwdbwd; do tail -1 $out/bench_$w.json | cut -c1-400; done
