@@ -92,8 +92,28 @@ template <typename T> MVR_HD V3<T> normalize_shared(const V3<T> &v, T eps, T *no
   return {div_by(v.x, d, y), div_by(v.y, d, y), div_by(v.z, d, y)};
 }
 
+// Gradient-only arithmetic (the backward kernels; no coverage or depth decision depends on it): the library is built with
+// -ffp-contract=off for the exact paths, and a helper defined outside a `#pragma clang fp contract(fast)` scope keeps its
+// separate multiplies and adds even when it is inlined into one — the backward's pixel loop had 124 v_mul + 65 v_add / v_sub
+// against 34 fused multiply-adds.  These variants carry the pragma themselves.
+template <typename T> MVR_HD T dot_c(const V3<T> &a, const V3<T> &b) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+  return (a.x * b.x + a.y * b.y) + a.z * b.z;
+}
+template <typename T> MVR_HD T edge_fn_c(T px, T py, T ax, T ay, T bx, T by) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+  return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
 // v / max(||v||, eps) through one reciprocal square root: inv_d = 1/max(||v||, eps); clamped <=> ||v|| <= eps.
 template <typename T> MVR_HD V3<T> normalize_rs(const V3<T> &v, T eps, T *inv_d, bool *clamped) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
   T n2 = (v.x * v.x + v.y * v.y) + v.z * v.z;
   *clamped = !(n2 > eps * eps);
   T r = trsq(tmax(n2, eps * eps));
@@ -101,8 +121,11 @@ template <typename T> MVR_HD V3<T> normalize_rs(const V3<T> &v, T eps, T *inv_d,
   return {v.x * r, v.y * r, v.z * r};
 }
 template <typename T> MVR_HD V3<T> normalize_rs_bwd(const V3<T> &out, T inv_d, bool clamped, const V3<T> &g) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
   if (clamped) return {g.x * inv_d, g.y * inv_d, g.z * inv_d};
-  T og = dot(out, g);
+  T og = dot_c(out, g);
   return {(g.x - out.x * og) * inv_d, (g.y - out.y * og) * inv_d, (g.z - out.z * og) * inv_d};
 }
 
@@ -565,12 +588,12 @@ template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_pre(cons
   V3<T> lh = cam.l;
   idl = (T)1; cl = true;
   if (!cam.l_is_unit) lh = normalize_rs(cam.l, (T)kNormalizeEps, &idl, &cl);
-  T cosang = dot(nh, lh);
+  T cosang = dot_c(nh, lh);
   bool lit = cosang > (T)0;
   V3<T> view = {cam.cc.x - p.x, cam.cc.y - p.y, cam.cc.z - p.z};
   V3<T> vh = normalize_rs(view, (T)kNormalizeEps, &idv, &cv);
   V3<T> refl = {-lh.x + (T)2 * (cosang * nh.x), -lh.y + (T)2 * (cosang * nh.y), -lh.z + (T)2 * (cosang * nh.z)};
-  T dvr = dot(vh, refl);
+  T dvr = dot_c(vh, refl);
   bool spec_on = lit && dvr > (T)0;
   T alpha = spec_on ? dvr : (T)0;
   T sc = cam.ph.ambient + cam.ph.diffuse * (lit ? cosang : (T)0);
@@ -594,7 +617,7 @@ template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_pre(cons
     V3<T> g_vh = {g_dvr * refl.x, g_dvr * refl.y, g_dvr * refl.z};
     V3<T> g_r = {g_dvr * vh.x, g_dvr * vh.y, g_dvr * vh.z};
     g_lh = {-g_r.x, -g_r.y, -g_r.z};
-    g_cos += (T)2 * dot(g_r, nh);
+    g_cos += (T)2 * dot_c(g_r, nh);
     g_nh = {(T)2 * cosang * g_r.x, (T)2 * cosang * g_r.y, (T)2 * cosang * g_r.z};
     V3<T> g_view = normalize_rs_bwd(vh, idv, cv, g_vh);
     g_cc = g_view;
@@ -609,9 +632,9 @@ template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_pre(cons
   u0 = fp.u0; v0 = fp.v0; z0 = fp.z0; u1 = fp.u1; v1 = fp.v1; z1 = fp.z1; u2 = fp.u2; v2 = fp.v2; z2 = fp.z2;
   ra = fp.ra;
   // barycentric gradients
-  T gw0 = (dot(g_p, X0) + dot(g_n, N0)) + dot(g_tex, c0);
-  T gw1 = (dot(g_p, X1) + dot(g_n, N1)) + dot(g_tex, c1);
-  T gw2 = (dot(g_p, X2) + dot(g_n, N2)) + dot(g_tex, c2);
+  T gw0 = (dot_c(g_p, X0) + dot_c(g_n, N0)) + dot_c(g_tex, c0);
+  T gw1 = (dot_c(g_p, X1) + dot_c(g_n, N1)) + dot_c(g_tex, c1);
+  T gw2 = (dot_c(g_p, X2) + dot_c(g_n, N2)) + dot_c(g_tex, c2);
   T ga0 = gw0, ga1 = gw1, ga2 = gw2, gz0 = (T)0, gz1 = (T)0, gz2 = (T)0;
   if (cam.persp) {
     T gt0, gt1, gt2;
