@@ -259,3 +259,38 @@ def test_soft_path_cuts_straddling_faces(oracle, shader, K, dist):
         grads.append([x.grad.clone() for x in (a, e, d)])
     assert all(torch.isfinite(g).all() for g in grads[0]) and float(grads[0][0].abs().max()) > 0
     assert all(torch.equal(g0, g1) for g0, g1 in zip(*grads))
+
+
+def test_full_c3_object_gradients_against_finite_differences(oracle):
+    """One whole object of BASELINE configs[2] — tier M, all 12 jittered views at 224 x 224, relative light — against fp64
+    central differences of the oracle with the pixel -> face maps held fixed (Weak 9).  The views are
+    independent, so ONE pair of oracle renders per parameter gives all 12 derivatives: every view's parameter moves by +-h
+    and the loss is taken per view (6 renders of 12 views instead of 72)."""
+    from mvtn_amd import MVRenderer, Meshes
+    v, f = syn.synthetic_mesh("M", 31)
+    V, size = 12, 224
+    az, el, di = _views(1, V, 32)
+    r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="relative").eval()
+    leaves = [_t(x).requires_grad_(True) for x in (az, el, di)]
+    images, _ = r([Meshes([v], [f])], None, *leaves)
+    kw = dict(obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
+    want = oracle.render_meshes([v], [f], az, el, di, size, light_dir=oracle.camera_position(az, el, di), **kw)
+    assert np.abs(images.detach().cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+    G = np.random.default_rng(33).normal(size=images.shape)
+    images.backward(_t(G))
+    v64 = v.astype(np.float64)
+    base = [x.astype(np.float64) for x in (az, el, di)]
+
+    def per_view_loss(a, e, d):
+        o = oracle.render_meshes([v64], [f], a, e, d, size, light_dir=oracle.camera_position(a, e, d, np.float64), dtype=np.float64,
+                                 fixed_p2f=want["pix_to_face"], **kw)
+        return (o["images"] * G).sum(axis=(0, 2, 3, 4))          # (V,)
+    for k, (name, h) in enumerate((("azim", 1e-4), ("elev", 1e-4), ("dist", 1e-5))):
+        plus, minus = [x.copy() for x in base], [x.copy() for x in base]
+        plus[k] += h
+        minus[k] -= h
+        ref = (per_view_loss(*plus) - per_view_loss(*minus)) / (2 * h)
+        got = leaves[k].grad.cpu().numpy().astype(np.float64)[0]
+        rel = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
+        print("%s: max relative error over the 12 views %.2e (|grad| up to %.3g)" % (name, rel, np.abs(ref).max()))
+        assert rel < 2e-3, (name, rel, got, ref)
