@@ -269,7 +269,7 @@ def main():
             return renderer(packed, None, azim, elev, dist_t)[0]
 
     # c5 on several GPUs: the step is the local render + the all-gather of the rendered views (north_star)
-    gather_in_step = fixed_total and world > 1 and not args.no_gather
+    gather_in_step = fixed_total and dist_on and not args.no_gather      # (dist_on at world 1 = --force-dist: the same code path, self-test)
     if gather_in_step:
         from mvtn_amd.distributed import all_gather_views, shard_counts
         counts = shard_counts(64, world)
