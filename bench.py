@@ -285,9 +285,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # untimed: max(W, 50) steps in all — a short --warmup (the driver passes 5) leaves clocks, caches and the allocator cold
-    prewarm = max(0, 50 - args.warmup)
-    for _ in range(prewarm + args.warmup):
+    # untimed: max(W, 300) steps in all — a short --warmup (the driver passes 5) leaves clocks, caches and the allocator cold
+    # (tools/fixed_cost.py: a 20-step region reads 104.5 us / step after 50 steps, 101.6 after 300, 97.6 in steady state).
+    # The W warm-up steps proper follow a synchronize of their own: the first launch after a long unsynchronised run pays
+    # the HIP runtime's clean-up of the completed commands (200-300 us on this box), which belongs to no step.
+    prewarm = max(0, (30 if soft else 300) - args.warmup)
+    for _ in range(prewarm):
+        out = step()
+    barrier()
+    for _ in range(args.warmup):
         out = step()
     elapsed = timed(step, args.steps, barrier, dist_on, dev)
     out = render()
