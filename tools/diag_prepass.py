@@ -25,7 +25,12 @@ lib.mvr_diag_set_buffer.argtypes = [ctypes.c_void_p]
 lib.mvr_diag_set_buffer(buf.data_ptr())
 r(packed, None, ta, te, td)
 torch.cuda.synchronize()
-d = buf.cpu().numpy()[(1 << 20):].reshape(-1, 8)[:B * V]
+dall = buf.cpu().numpy()[(1 << 20):].reshape(-1, 8)
+d = dall[:B * V]
+if (d[:, 6] > 0).all():   # finer stamps inside the fused look-at
+    x = dall[2048:2048 + B * V, 0]
+    print("look-at: start -> angles loaded %.0f, sincos %.0f, look-at + validity %.0f, publish + barriers %.0f cycles" % (
+        (d[:, 6] - d[:, 0]).mean(), (d[:, 7] - d[:, 6]).mean(), (x - d[:, 7]).mean(), (d[:, 5] - x).mean()))
 names = ["project verts", "faces: bins + histogram", "scan", "fill lists"]
 for k, nm in enumerate(names):
     dt = (d[:, k + 1] - d[:, k]).astype(np.float64)
