@@ -550,35 +550,16 @@ template <typename T> MVR_HD FaceProjected<T> face_project_for_bwd(const PixelGr
   return f;
 }
 
-// `mid` runs between the shading part and the geometric part.  The face's data (fp, X, N) are not used across it: a caller
-// that holds them in fast memory may let `mid` re-read them there (they are passed by reference and read again after it)
-// instead of keeping ~40 registers alive through the shading arithmetic (k_mesh_backward_tab).
-struct NoMid { MVR_HD void operator()() const {} };
-template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_pre(const PixelGradIn<T> &cam, T px, T py, const FaceProjected<T> &fp,
-                                                      const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
-                                                      const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
-                                                      const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
-                                                      const V3<T> &G, T acc[18], Mid mid = Mid()) {
-  // Gradient arithmetic: no coverage decision depends on it, so quotients go through shared reciprocals
-  // (trcp / trsq) and the compiler may contract multiply-adds.
+// The shading half of the per-pixel backward: barycentrics w -> (p, n, tex) -> Phong -> upstream gradient G back to
+// g_p, g_n, g_tex (gradients of the interpolated position / normal / texel), the camera centre and the light.
+template <typename T> MVR_HD void phong_shade_bwd(const PixelGradIn<T> &cam, T w0, T w1, T w2,
+                                                  const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
+                                                  const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
+                                                  const V3<T> &c0, const V3<T> &c1, const V3<T> &c2, const V3<T> &G,
+                                                  V3<T> *g_p_out, V3<T> *g_n_out, V3<T> *g_tex_out, V3<T> *g_cc_out, V3<T> *g_l_out) {
 #if defined(__clang__)
 #pragma clang fp contract(fast)
 #endif
-  // ---- forward recompute -------------------------------------------------
-  T rz0 = fp.rz0, rz1 = fp.rz1, rz2 = fp.rz2;
-  T u0 = fp.u0, v0 = fp.v0, z0 = fp.z0, u1 = fp.u1, v1 = fp.v1, z1 = fp.z1, u2 = fp.u2, v2 = fp.v2, z2 = fp.z2;
-  T ra = fp.ra;
-  T e0 = edge_fn(px, py, u1, v1, u2, v2), e1 = edge_fn(px, py, u2, v2, u0, v0), e2 = edge_fn(px, py, u0, v0, u1, v1);
-  T a0 = e0 * ra, a1 = e1 * ra, a2 = e2 * ra;
-  T w0 = a0, w1 = a1, w2 = a2, rden = (T)1;
-  bool den_clamped = false;
-  if (cam.persp) {
-    T t0 = (a0 * z1) * z2, t1 = (z0 * a1) * z2, t2 = (z0 * z1) * a2;
-    T sum = (t0 + t1) + t2;
-    rden = trcp(tmax(sum, (T)kEps));
-    den_clamped = !(sum > (T)kEps);
-    w0 = t0 * rden; w1 = t1 * rden; w2 = t2 * rden;
-  }
   V3<T> p = {(w0 * X0.x + w1 * X1.x) + w2 * X2.x, (w0 * X0.y + w1 * X1.y) + w2 * X2.y, (w0 * X0.z + w1 * X1.z) + w2 * X2.z};
   V3<T> n = {(w0 * N0.x + w1 * N1.x) + w2 * N2.x, (w0 * N0.y + w1 * N1.y) + w2 * N2.y, (w0 * N0.z + w1 * N1.z) + w2 * N2.z};
   V3<T> tex = {(w0 * c0.x + w1 * c1.x) + w2 * c2.x, (w0 * c0.y + w1 * c1.y) + w2 * c2.y, (w0 * c0.z + w1 * c1.z) + w2 * c2.z};
@@ -627,6 +608,40 @@ template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_pre(cons
   g_lh = {g_lh.x + g_cos * nh.x, g_lh.y + g_cos * nh.y, g_lh.z + g_cos * nh.z};
   V3<T> g_n = normalize_rs_bwd(nh, idn, cn, g_nh);
   V3<T> g_l = cam.l_is_unit ? g_lh : normalize_rs_bwd(lh, idl, cl, g_lh);
+  *g_p_out = g_p; *g_n_out = g_n; *g_tex_out = g_tex; *g_cc_out = g_cc; *g_l_out = g_l;
+}
+
+// `mid` runs between the shading part and the geometric part.  The face's data (fp, X, N) are not used across it: a caller
+// that holds them in fast memory may let `mid` re-read them there (they are passed by reference and read again after it)
+// instead of keeping ~40 registers alive through the shading arithmetic (k_mesh_backward_tab).
+struct NoMid { MVR_HD void operator()() const {} };
+template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_pre(const PixelGradIn<T> &cam, T px, T py, const FaceProjected<T> &fp,
+                                                      const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
+                                                      const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
+                                                      const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
+                                                      const V3<T> &G, T acc[18], Mid mid = Mid()) {
+  // Gradient arithmetic: no coverage decision depends on it, so quotients go through shared reciprocals
+  // (trcp / trsq) and the compiler may contract multiply-adds.
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+  // ---- forward recompute -------------------------------------------------
+  T rz0 = fp.rz0, rz1 = fp.rz1, rz2 = fp.rz2;
+  T u0 = fp.u0, v0 = fp.v0, z0 = fp.z0, u1 = fp.u1, v1 = fp.v1, z1 = fp.z1, u2 = fp.u2, v2 = fp.v2, z2 = fp.z2;
+  T ra = fp.ra;
+  T e0 = edge_fn(px, py, u1, v1, u2, v2), e1 = edge_fn(px, py, u2, v2, u0, v0), e2 = edge_fn(px, py, u0, v0, u1, v1);
+  T a0 = e0 * ra, a1 = e1 * ra, a2 = e2 * ra;
+  T w0 = a0, w1 = a1, w2 = a2, rden = (T)1;
+  bool den_clamped = false;
+  if (cam.persp) {
+    T t0 = (a0 * z1) * z2, t1 = (z0 * a1) * z2, t2 = (z0 * z1) * a2;
+    T sum = (t0 + t1) + t2;
+    rden = trcp(tmax(sum, (T)kEps));
+    den_clamped = !(sum > (T)kEps);
+    w0 = t0 * rden; w1 = t1 * rden; w2 = t2 * rden;
+  }
+  V3<T> g_p, g_n, g_tex, g_cc, g_l;
+  phong_shade_bwd(cam, w0, w1, w2, X0, X1, X2, N0, N1, N2, c0, c1, c2, G, &g_p, &g_n, &g_tex, &g_cc, &g_l);
   mid();
   rz0 = fp.rz0; rz1 = fp.rz1; rz2 = fp.rz2;
   u0 = fp.u0; v0 = fp.v0; z0 = fp.z0; u1 = fp.u1; v1 = fp.v1; z1 = fp.z1; u2 = fp.u2; v2 = fp.v2; z2 = fp.z2;
@@ -678,12 +693,73 @@ template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_pre(cons
   acc[15] += g_l.x; acc[16] += g_l.y; acc[17] += g_l.z;
 }
 
+// The perspective-correct case in RAY form.  The perspective-correct barycentrics of pixel (px, py) are the barycentrics
+// of the point where its ray d = (px / s, py / s, 1) meets the face's plane in VIEW space (bary_ray above):
+//     w_i = c_i / (c_0 + c_1 + c_2),  c_0 = d . (v1 x v2), c_1 = d . (v2 x v0), c_2 = d . (v0 x v1)
+// with the cross products a per-FACE constant, and their gradient goes to the view-space vertices directly:
+//     h_i = (dL/dw_i - sum_j dL/dw_j w_j) / sum c ;  dL/dv0 = d x (h1 v2 - h2 v1), dL/dv1 = d x (h2 v0 - h0 v2), dL/dv2 = d x (h0 v1 - h1 v0)
+// — no projected vertices, no edge functions, no division by a vertex depth (finite for vertices at or behind the camera
+// plane): ~55 operations per pixel where the projected form (phong_pixel_bwd_pre) spends ~125 on the same two steps.  The
+// kEps clamps of the forward's quotients are not reproduced (they act on faces the rasteriser culls); a ray parallel to
+// the face's plane (sum c = 0) contributes nothing.
+template <typename T> struct FaceView { V3<T> v0, v1, v2, n0, n1, n2; };   // view-space vertices; n0 = v1 x v2, n1 = v2 x v0, n2 = v0 x v1
+template <typename T> MVR_HD FaceView<T> face_view_for_bwd(const PixelGradIn<T> &cam, const V3<T> &X0, const V3<T> &X1, const V3<T> &X2) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+  FaceView<T> f;
+  f.v0 = world_to_view(cam.R, cam.Tr, X0); f.v1 = world_to_view(cam.R, cam.Tr, X1); f.v2 = world_to_view(cam.R, cam.Tr, X2);
+  f.n0 = {f.v1.y * f.v2.z - f.v1.z * f.v2.y, f.v1.z * f.v2.x - f.v1.x * f.v2.z, f.v1.x * f.v2.y - f.v1.y * f.v2.x};
+  f.n1 = {f.v2.y * f.v0.z - f.v2.z * f.v0.y, f.v2.z * f.v0.x - f.v2.x * f.v0.z, f.v2.x * f.v0.y - f.v2.y * f.v0.x};
+  f.n2 = {f.v0.y * f.v1.z - f.v0.z * f.v1.y, f.v0.z * f.v1.x - f.v0.x * f.v1.z, f.v0.x * f.v1.y - f.v0.y * f.v1.x};
+  return f;
+}
+// (`mid` as in phong_pixel_bwd_pre: fv.n* and X, N are read before it, X, N and fv.v* after it)
+template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_ray(const PixelGradIn<T> &cam, T px, T py, const FaceView<T> &fv,
+                                                      const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
+                                                      const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
+                                                      const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
+                                                      const V3<T> &G, T acc[18], Mid mid = Mid()) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+  const T inv_s = trcp(cam.s);
+  const T dx = px * inv_s, dy = py * inv_s;
+  const T k0 = (fv.n0.z + dx * fv.n0.x) + dy * fv.n0.y, k1 = (fv.n1.z + dx * fv.n1.x) + dy * fv.n1.y, k2 = (fv.n2.z + dx * fv.n2.x) + dy * fv.n2.y;
+  const T sum = (k0 + k1) + k2;
+  const T r = sum != (T)0 ? trcp(sum) : (T)0;
+  const T w0 = k0 * r, w1 = k1 * r, w2 = k2 * r;
+  V3<T> g_p, g_n, g_tex, g_cc, g_l;
+  phong_shade_bwd(cam, w0, w1, w2, X0, X1, X2, N0, N1, N2, c0, c1, c2, G, &g_p, &g_n, &g_tex, &g_cc, &g_l);
+  mid();
+  const T gw0 = (dot_c(g_p, X0) + dot_c(g_n, N0)) + dot_c(g_tex, c0);
+  const T gw1 = (dot_c(g_p, X1) + dot_c(g_n, N1)) + dot_c(g_tex, c1);
+  const T gw2 = (dot_c(g_p, X2) + dot_c(g_n, N2)) + dot_c(g_tex, c2);
+  const T gs = (gw0 * w0 + gw1 * w1) + gw2 * w2;
+  const T h0 = (gw0 - gs) * r, h1 = (gw1 - gs) * r, h2 = (gw2 - gs) * r;
+  const V3<T> v0 = fv.v0, v1 = fv.v1, v2 = fv.v2;
+  const V3<T> Y0 = {h1 * v2.x - h2 * v1.x, h1 * v2.y - h2 * v1.y, h1 * v2.z - h2 * v1.z};
+  const V3<T> Y1 = {h2 * v0.x - h0 * v2.x, h2 * v0.y - h0 * v2.y, h2 * v0.z - h0 * v2.z};
+  const V3<T> Y2 = {h0 * v1.x - h1 * v0.x, h0 * v1.y - h1 * v0.y, h0 * v1.z - h1 * v0.z};
+  auto vert = [&](const V3<T> &Y, const V3<T> &Xw) {   // d x Y with d = (dx, dy, 1), then R / T through Xv = Xw R + T
+    const T gx = dy * Y.z - Y.y, gy = Y.x - dx * Y.z, gz = dx * Y.y - dy * Y.x;
+    acc[0] += Xw.x * gx; acc[1] += Xw.x * gy; acc[2] += Xw.x * gz;
+    acc[3] += Xw.y * gx; acc[4] += Xw.y * gy; acc[5] += Xw.y * gz;
+    acc[6] += Xw.z * gx; acc[7] += Xw.z * gy; acc[8] += Xw.z * gz;
+    acc[9] += gx; acc[10] += gy; acc[11] += gz;
+  };
+  vert(Y0, X0); vert(Y1, X1); vert(Y2, X2);
+  acc[12] += g_cc.x; acc[13] += g_cc.y; acc[14] += g_cc.z;
+  acc[15] += g_l.x; acc[16] += g_l.y; acc[17] += g_l.z;
+}
+
 template <typename T> MVR_HD void phong_pixel_bwd(const PixelGradIn<T> &cam, T px, T py,
                                                   const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
                                                   const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
                                                   const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
                                                   const V3<T> &G, T acc[18]) {
-  phong_pixel_bwd_pre(cam, px, py, face_project_for_bwd(cam, X0, X1, X2), X0, X1, X2, N0, N1, N2, c0, c1, c2, G, acc);
+  if (cam.persp) phong_pixel_bwd_ray(cam, px, py, face_view_for_bwd(cam, X0, X1, X2), X0, X1, X2, N0, N1, N2, c0, c1, c2, G, acc);
+  else phong_pixel_bwd_pre(cam, px, py, face_project_for_bwd(cam, X0, X1, X2), X0, X1, X2, N0, N1, N2, c0, c1, c2, G, acc);
 }
 
 
