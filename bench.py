@@ -400,6 +400,20 @@ def main():
         except Exception as exc:   # (a capture failure must not lose the measured line)
             graphed = {"error": str(exc)[:200]}
 
+    # ---- C3, beside `value`: the same eager step with the autograd engine's worker threads off
+    # (torch.autograd.set_multithreading_enabled(False): the backward then runs on the calling thread).  With one device the
+    # worker thread only adds two thread hand-overs per step; how long they take depends on what the host's cores were doing
+    # (tools/host_autograd_mt.py: 178 us of host time per step cold, 103 warm, 85 with the switch), so the default line swings
+    # between host-bound and GPU-bound from run to run and this one does not.
+    single_thread = None
+    if args.workload == "mesh_fwdbwd" and not args.host_meshes and not args.no_pipelined and hasattr(torch.autograd, "set_multithreading_enabled"):
+        with torch.autograd.set_multithreading_enabled(False):
+            for _ in range(min(args.warmup, 50)):
+                render()
+            ts_ = timed(render, args.steps, barrier, dist_on, dev)
+        single_thread = {"views_per_s": n_views_total * args.steps / ts_, "ms_per_step": ts_ / args.steps * 1e3,
+                         "note": "eager, torch.autograd.set_multithreading_enabled(False)"}
+
     # ---- the all-gather of rendered views the north_star names: inside `value` for c5 on several GPUs (above); for the
     # weak-scaling workloads timed here, beside `value`
     gather = None
@@ -507,6 +521,8 @@ def main():
             line["two_streams"] = pipelined
         if graphed:
             line["hip_graph_replay"] = graphed
+        if single_thread is not None:
+            line["eager_autograd_single_thread"] = single_thread
         sys.stdout.flush()
         try:
             ctypes.CDLL(None).fflush(None)   # C stdio of the libraries (the RCCL banner is buffered there): out to stderr now

@@ -184,9 +184,17 @@ def with_window(params, scale=None, flip=None, crop_i=None, crop_j=None, pad=0):
 
 
 def _copy_params(params, extra_flags):
-    p = _lib.MeshParams.from_buffer_copy(params)
-    p.flags |= extra_flags
-    p._keep = getattr(params, "_keep", None)
+    """`params` with extra flag bits; the variants are remembered on the params object (a training step asks for the same two
+    every time: copying the ctypes struct costs ~4 us of host time per call)."""
+    cache = params.__dict__.setdefault("_variants", {})
+    p = cache.get(extra_flags)
+    src = bytes(params)   # (a caller may have changed a field of `params` since the variant was made)
+    if p is None or p._src_bytes != src:
+        p = _lib.MeshParams.from_buffer_copy(params)
+        p._src_bytes = src
+        p.flags |= extra_flags
+        p._keep = getattr(params, "_keep", None)
+        cache[extra_flags] = p
     return p
 
 
@@ -303,7 +311,8 @@ class _RenderMeshViews(torch.autograd.Function):
                                                           aux_p, aux_p + 4 * N, R.data_ptr(), T.data_ptr(), light_p,
                                                           1 if ctx.relative else 0, p2f.data_ptr(), _f32c(g).data_ptr(), gp, gp + 4 * N,
                                                           gp + 8 * N, ws.data_ptr(), ws.numel(), st), "mvr_render_mesh_views_backward")
-            return grads[0], grads[1], grads[2], None, None, None, None, None, None, None
+            ga, ge, gd = grads.unbind(0)   # (one call for the three views)
+            return ga, ge, gd, None, None, None, None, None, None, None
         # somebody also differentiated through the returned cameras (or only through them): chain the three backwards
         gR_c, gT_c = torch.zeros(N, 3, 3, dtype=torch.float32, device=dev), torch.zeros(N, 3, dtype=torch.float32, device=dev)
         gL = torch.zeros(N, 3, dtype=torch.float32, device=dev) if ctx.relative else None
@@ -331,8 +340,9 @@ def render_mesh_views(packed: PackedMeshes, azim, elev, dist, light_dir, params,
     path of models/renderer.py:65-114 as one differentiable call.  light_dir: (1,3) / (N,3) tensor, or None for the
     reference's "relative" light (camera position of every view, differentiable).  status as in look_at_view_transform."""
     need_grad = torch.is_grad_enabled() and (azim.requires_grad or elev.requires_grad or dist.requires_grad)
-    return _RenderMeshViews.apply(azim.reshape(-1), elev.reshape(-1), dist.reshape(-1), packed, params, light_dir,
-                                  max_trials, seed, host_status, need_grad)
+    if azim.dim() != 1:   # (the renderer hands over flat views already: a second reshape is another tensor object each)
+        azim, elev, dist = azim.reshape(-1), elev.reshape(-1), dist.reshape(-1)
+    return _RenderMeshViews.apply(azim, elev, dist, packed, params, light_dir, max_trials, seed, host_status, need_grad)
 
 
 def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params, return_redo=False, return_straddlers=False):

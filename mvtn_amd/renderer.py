@@ -31,6 +31,29 @@ EXAHSTION_LIMIT = 20  # models/renderer.py:30 (the reference's spelling)
 _STATUS_PENDING = -1   # sentinel in the pinned status words until the look-at kernel has written them
 
 
+class _CallState:
+    """Mutable per-renderer bookkeeping of the "device" rotation check (kept off the nn.Module's attribute machinery)."""
+    __slots__ = ("calls", "pending", "pool")
+
+    def __init__(self):
+        self.calls = 0
+        self.pending = []   # status words (written by the kernel) of earlier forwards
+        self.pool = []      # recycled status words
+
+
+class _StatusWords:
+    """Two pinned int32 words a kernel writes directly, with a numpy view for the host side and the device-visible address."""
+    __slots__ = ("tensor", "np", "ptr")
+
+    def __init__(self):
+        self.tensor = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        self.np = self.tensor.numpy()
+        self.ptr = self.tensor.data_ptr()
+
+    def data_ptr(self):
+        return self.ptr
+
+
 class MVRenderer(nn.Module):
     def __init__(self, nb_views, image_size=224, pc_rendering=True, object_color="white", background_color="white",
                  faces_per_pixel=1, points_radius=0.006, points_per_pixel=1, light_direction="random",
@@ -61,9 +84,9 @@ class MVRenderer(nn.Module):
         if rotation_check not in ("device", "sync", "off"):
             raise ValueError("rotation_check must be 'device', 'sync' or 'off'")
         self.rotation_check = rotation_check
-        self._calls = 0
-        self._pending = []  # pinned status words (written by the kernel) of earlier forwards, "device" mode
-        self._status_pool = []  # recycled pinned status buffers
+        # per-call bookkeeping lives in a plain object: assigning an attribute of an nn.Module goes through Module.__setattr__
+        # (~3 us each on the host, twice per forward)
+        self._st = _CallState()
         self._light_cache = {}  # (device, direction tuple) -> (1,3) tensor
         self._color_cache = {}  # colour name -> 3 floats
         self._params_cache = {}
@@ -118,40 +141,45 @@ class MVRenderer(nn.Module):
 
     def _device_remedy_args(self):
         """(max_trials, seed, pinned status words) of one forward in "device" mode."""
-        self.check_status(block=False)
-        self._calls += 1
-        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        st = self._st
+        if st.pending:
+            self.check_status(block=False)
+        st.calls += 1
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + st.calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
         # 2 pinned int32 words the kernel writes directly (zero-copy).  They are pre-set to a sentinel, so
         # "has this forward's status landed?" is a plain host read: no event, no copy, nothing on the stream.
-        host = self._status_pool.pop() if self._status_pool else torch.empty(2, dtype=torch.int32, pin_memory=True)
-        host.fill_(_STATUS_PENDING)
-        self._pending.append(host)
+        # (read and written through a numpy view of the pinned tensor: a torch indexing op costs ~2 us, this ~0.1)
+        host = st.pool.pop() if st.pool else _StatusWords()
+        host.np[:] = _STATUS_PENDING
+        st.pending.append(host)
         return EXAHSTION_LIMIT, seed, host
 
     def _forget_status(self, host):
         """The launch that should have written `host` failed before reaching the GPU: take it out of the pending list."""
         if host is not None:
-            self._pending = [h for h in self._pending if h is not host]
-            self._status_pool.append(host)
+            st = self._st
+            st.pending = [h for h in st.pending if h is not host]
+            st.pool.append(host)
 
     def check_status(self, block=True):
         """Raise the reference's sys.exit("Remedy did not work") if an earlier forward exhausted the
         device-side remedy.  block=False only looks at status words that have already landed."""
+        st = self._st
         keep = []
-        for host in self._pending:
-            if int(host[1]) == _STATUS_PENDING:
+        for host in st.pending:
+            if int(host.np[1]) == _STATUS_PENDING:
                 if not block:
                     keep.append(host)
                     continue
                 torch.cuda.synchronize()
-                if int(host[1]) == _STATUS_PENDING:   # still the sentinel after a full synchronise: never launched
-                    self._status_pool.append(host)
+                if int(host.np[1]) == _STATUS_PENDING:   # still the sentinel after a full synchronise: never launched
+                    st.pool.append(host)
                     continue
-            if int(host[1]) != 0:
-                self._pending = []
+            if int(host.np[1]) != 0:
+                st.pending = []
                 sys.exit("Remedy did not work")
-            self._status_pool.append(host)
-        self._pending = keep
+            st.pool.append(host)
+        st.pending = keep
 
     def _remedy(self, azim, elev, dist):
         """Host-driven random re-draw of ALL views until every R is valid (ops.py:156-165), "sync" mode."""
@@ -172,7 +200,7 @@ class MVRenderer(nn.Module):
         if torch.is_tensor(color) and color.dim() >= 2:  # "custom": per-vertex colours (B, >=Vn, 3)
             vert_colors, obj = color, (1.0, 1.0, 1.0)
         else:
-            obj = [float(c) for c in color]
+            obj = color if isinstance(color, tuple) else tuple(float(c) for c in color)
         if isinstance(meshes, PackedMeshes):
             packed = meshes
             if vert_colors is not None and packed.vert_colors is None:
@@ -193,15 +221,19 @@ class MVRenderer(nn.Module):
                 if self.light_direction_type == "fixed":
                     self._light_cache[key] = light
         n_light = N if light is None else light.shape[0]
-        pkey = (n_light, tuple(obj), tuple(float(c) for c in background_color), bool(self.cull_backfaces),
-                bool(self.perspective_correct), self.strip_rows, self.nb_views, self.image_size, self.z_clip, self.normalize,
-                self.fov_scale, self.normals_three_cross)
+        # (the key holds the attribute objects as they are — the colours arrive as tuples of floats from _named_color — so that
+        # building it costs one tuple, not a dozen conversions, per forward)
+        pkey = (n_light, obj if isinstance(obj, tuple) else tuple(obj),
+                background_color if isinstance(background_color, tuple) else tuple(float(c) for c in background_color),
+                self.cull_backfaces, self.perspective_correct, self.strip_rows, self.nb_views, self.image_size, self.z_clip,
+                self.normalize, self.fov_scale, self.normals_three_cross, self.shader)
         params = self._params_cache.get(pkey)
         if params is None:
             if len(self._params_cache) > 64:
                 self._params_cache.clear()
-            params = self._params_cache[pkey] = F.mesh_params(self.nb_views, self.image_size, n_light, pkey[1], pkey[2],
-                                                              cull_backfaces=pkey[3], perspective_correct=pkey[4],
+            params = self._params_cache[pkey] = F.mesh_params(self.nb_views, self.image_size, n_light, tuple(float(c) for c in pkey[1]),
+                                                              tuple(float(c) for c in pkey[2]),
+                                                              cull_backfaces=bool(pkey[3]), perspective_correct=bool(pkey[4]),
                                                               strip_rows=self.strip_rows, z_clip=self.z_clip,
                                                               normalize=self.normalize if self.shader == "hard_phong" else None,
                                                               fov_scale=self.fov_scale, normals_three_cross=self.normals_three_cross)
