@@ -552,7 +552,9 @@ template <typename T> MVR_HD FaceProjected<T> face_project_for_bwd(const PixelGr
 
 // The shading half of the per-pixel backward: barycentrics w -> (p, n, tex) -> Phong -> upstream gradient G back to
 // g_p, g_n, g_tex (gradients of the interpolated position / normal / texel), the camera centre and the light.
-template <typename T> MVR_HD void phong_shade_bwd(const PixelGradIn<T> &cam, T w0, T w1, T w2,
+// FLAT: the three vertex colours are the same (a constant object colour): the texel is that colour for any barycentrics that
+// sum to one — what the fast rasteriser's shading assumes too — so it is not interpolated and carries no gradient.
+template <typename T, bool FLAT = false> MVR_HD void phong_shade_bwd(const PixelGradIn<T> &cam, T w0, T w1, T w2,
                                                   const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
                                                   const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
                                                   const V3<T> &c0, const V3<T> &c1, const V3<T> &c2, const V3<T> &G,
@@ -562,7 +564,8 @@ template <typename T> MVR_HD void phong_shade_bwd(const PixelGradIn<T> &cam, T w
 #endif
   V3<T> p = {(w0 * X0.x + w1 * X1.x) + w2 * X2.x, (w0 * X0.y + w1 * X1.y) + w2 * X2.y, (w0 * X0.z + w1 * X1.z) + w2 * X2.z};
   V3<T> n = {(w0 * N0.x + w1 * N1.x) + w2 * N2.x, (w0 * N0.y + w1 * N1.y) + w2 * N2.y, (w0 * N0.z + w1 * N1.z) + w2 * N2.z};
-  V3<T> tex = {(w0 * c0.x + w1 * c1.x) + w2 * c2.x, (w0 * c0.y + w1 * c1.y) + w2 * c2.y, (w0 * c0.z + w1 * c1.z) + w2 * c2.z};
+  V3<T> tex = c0;
+  if (!FLAT) tex = {(w0 * c0.x + w1 * c1.x) + w2 * c2.x, (w0 * c0.y + w1 * c1.y) + w2 * c2.y, (w0 * c0.z + w1 * c1.z) + w2 * c2.z};
   T idn, idl, idv;
   bool cn, cl, cv;
   V3<T> nh = normalize_rs(n, (T)kNormalizeEps, &idn, &cn);
@@ -715,7 +718,9 @@ template <typename T> MVR_HD FaceView<T> face_view_for_bwd(const PixelGradIn<T> 
   return f;
 }
 // (`mid` as in phong_pixel_bwd_pre: fv.n* and X, N are read before it, X, N and fv.v* after it)
-template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_ray(const PixelGradIn<T> &cam, T px, T py, const FaceView<T> &fv,
+// FLAT (constant object colour): a term common to the three dL/dw_i cancels in h_i when the barycentrics sum to one, and the
+// texel's contribution dot(g_tex, c) is such a term — it is left out, with the texel's interpolation (phong_shade_bwd).
+template <typename T, typename Mid = NoMid, bool FLAT = false> MVR_HD void phong_pixel_bwd_ray(const PixelGradIn<T> &cam, T px, T py, const FaceView<T> &fv,
                                                       const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
                                                       const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
                                                       const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
@@ -730,11 +735,10 @@ template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_ray(cons
   const T r = sum != (T)0 ? trcp(sum) : (T)0;
   const T w0 = k0 * r, w1 = k1 * r, w2 = k2 * r;
   V3<T> g_p, g_n, g_tex, g_cc, g_l;
-  phong_shade_bwd(cam, w0, w1, w2, X0, X1, X2, N0, N1, N2, c0, c1, c2, G, &g_p, &g_n, &g_tex, &g_cc, &g_l);
+  phong_shade_bwd<T, FLAT>(cam, w0, w1, w2, X0, X1, X2, N0, N1, N2, c0, c1, c2, G, &g_p, &g_n, &g_tex, &g_cc, &g_l);
   mid();
-  const T gw0 = (dot_c(g_p, X0) + dot_c(g_n, N0)) + dot_c(g_tex, c0);
-  const T gw1 = (dot_c(g_p, X1) + dot_c(g_n, N1)) + dot_c(g_tex, c1);
-  const T gw2 = (dot_c(g_p, X2) + dot_c(g_n, N2)) + dot_c(g_tex, c2);
+  T gw0 = dot_c(g_p, X0) + dot_c(g_n, N0), gw1 = dot_c(g_p, X1) + dot_c(g_n, N1), gw2 = dot_c(g_p, X2) + dot_c(g_n, N2);
+  if (!FLAT) { gw0 += dot_c(g_tex, c0); gw1 += dot_c(g_tex, c1); gw2 += dot_c(g_tex, c2); }
   const T gs = (gw0 * w0 + gw1 * w1) + gw2 * w2;
   const T h0 = (gw0 - gs) * r, h1 = (gw1 - gs) * r, h2 = (gw2 - gs) * r;
   const V3<T> v0 = fv.v0, v1 = fv.v1, v2 = fv.v2;
