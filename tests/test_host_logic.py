@@ -386,3 +386,31 @@ def test_regularize_composition_is_pinned_to_the_reference():
         torch.manual_seed(int(seed))
         got = regularize_composition(x, float(p), bool(aug), float(cr))
         assert np.array_equal(got.numpy(), fx["y_" + str(name)]), name
+
+
+def test_flag_variants_of_the_params_struct_follow_their_source():
+    """The autograd nodes ask for the same two flag variants of a params struct on every step; they are remembered on the
+    struct (functional._copy_params) — and must be rebuilt when the caller changes a field of the source afterwards."""
+    from mvtn_amd import _lib, functional as F
+    p = F.mesh_params(12, 224, 1, (1.0, 1.0, 1.0), (1.0, 1.0, 1.0))
+    a = F._copy_params(p, _lib.MVR_KEEP_PIXEL_LISTS)
+    assert a is F._copy_params(p, _lib.MVR_KEEP_PIXEL_LISTS)                 # remembered
+    assert a.flags == p.flags | _lib.MVR_KEEP_PIXEL_LISTS and a.strip_rows == p.strip_rows
+    b = F._copy_params(p, _lib.MVR_WORKSPACE_FROM_FORWARD)
+    assert b is not a and b.flags == p.flags | _lib.MVR_WORKSPACE_FROM_FORWARD
+    p.strip_rows = 5                                                          # the caller edits the source
+    a2 = F._copy_params(p, _lib.MVR_KEEP_PIXEL_LISTS)
+    assert a2 is not a and a2.strip_rows == 5
+    p.flags |= _lib.MVR_BACKWARD_GATHER
+    assert F._copy_params(p, _lib.MVR_KEEP_PIXEL_LISTS).flags == p.flags | _lib.MVR_KEEP_PIXEL_LISTS
+
+
+def test_renderer_bookkeeping_is_not_module_state():
+    """The per-call status words of the device-side rotation check live in a plain object (assigning nn.Module attributes
+    costs microseconds per forward) and do not show up as parameters, buffers or sub-modules."""
+    from mvtn_amd import MVRenderer
+    r = MVRenderer(4, 32, pc_rendering=False)
+    assert len(list(r.parameters())) == 0 and len(list(r.buffers())) == 0 and len(list(r.children())) == 0
+    assert r._st.calls == 0 and r._st.pending == [] and r._st.pool == []
+    r.check_status()   # nothing pending: returns
+    assert r.state_dict() == {}
