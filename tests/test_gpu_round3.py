@@ -294,3 +294,28 @@ def test_full_c3_object_gradients_against_finite_differences(oracle):
         rel = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
         print("%s: max relative error over the 12 views %.2e (|grad| up to %.3g)" % (name, rel, np.abs(ref).max()))
         assert rel < 2e-3, (name, rel, got, ref)
+
+
+@pytest.mark.parametrize("size,strip_rows,tier", [(224, 0, "L"), (224, 16, "L"), (256, 16, "L"), (256, 32, "M"), (100, 5, "L"), (64, 32, "L"), (37, 3, "M")])
+def test_fast_rasteriser_lds_layouts_against_the_exact_kernel(size, strip_rows, tier):
+    """The fast rasteriser's shading table runs over the key, record and item areas of the workgroup's LDS and the
+    covered-pixel list carries 32-bit entries; both are sized from the strip's shape.  Other strip shapes than the
+    default 224 x 8 — and dense meshes, whose strips need several table passes — against the exact kernel: identical
+    pixel -> face maps, colours within the two kernels' shading tolerance."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = zip(*[syn.synthetic_mesh(tier, 40 + i) for i in range(2)])
+    V = 6
+    az, el, di = _views(2, V, 11)
+    packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl]), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
+    out = {}
+    for mode in ("fast", "exact"):
+        params = F.mesh_params(V, size, 1, (0.9, 0.8, 0.7), (1.0, 1.0, 1.0), exact_raster=(mode == "exact"), strip_rows=strip_rows)
+        img, p2f, cnt = F.render_meshes_fragments(packed, R, T, light, params, return_redo=True)
+        torch.cuda.synchronize()
+        out[mode] = (img.cpu().numpy(), p2f.cpu().numpy(), int(cnt.item()))
+    assert (out["exact"][1] >= 0).mean() > 0.1, "the object must cover part of the frame"
+    assert np.array_equal(out["fast"][1], out["exact"][1]), "%d pixels differ" % int((out["fast"][1] != out["exact"][1]).sum())
+    assert np.abs(out["fast"][0] - out["exact"][0]).max() <= 5e-5
