@@ -265,10 +265,24 @@ template <typename T> MVR_HD bool rotation_valid(const T M[9], T tol) {
 }
 
 // backward of look_at: gR[9] (dL/dR row-major), gT[3] -> g_azim, g_elev, g_dist (degrees).
-template <typename T> MVR_HD void look_at_bwd(T azim, T elev, T dist, const T gR[9], const T gT[3], T *g_azim, T *g_elev, T *g_dist) {
+// The part of look_at_bwd that does not need the upstream gradients (the forward recomputed: two sin / cos pairs, three
+// normalisations) and the part that does: a caller whose gradients arrive late (k_mesh_views_backward_finalize: they are sums
+// over the strips' partials) evaluates the first while it waits for them.  look_at_bwd below is the two in a row.
+template <typename T> struct LookAtFwd { LookAtState<T> st; T se, ce, sa, ca; };
+template <typename T> MVR_HD LookAtFwd<T> look_at_fwd_state(T azim, T elev, T dist) {
+  LookAtFwd<T> f;
+  sincos_deg(elev, &f.se, &f.ce);
+  sincos_deg(azim, &f.sa, &f.ca);
   T R[9], Tr[3];
-  LookAtState<T> st;
-  look_at(azim, elev, dist, R, Tr, &st);
+  look_at_from_position(camera_position_sc(f.se, f.ce, f.sa, f.ca, dist), R, Tr, &f.st);
+  return f;
+}
+template <typename T> MVR_HD void look_at_bwd_from_state(const LookAtFwd<T> &fw, T dist, const T gR[9], const T gT[3], T *g_azim, T *g_elev, T *g_dist);
+template <typename T> MVR_HD void look_at_bwd(T azim, T elev, T dist, const T gR[9], const T gT[3], T *g_azim, T *g_elev, T *g_dist) {
+  look_at_bwd_from_state(look_at_fwd_state(azim, elev, dist), dist, gR, gT, g_azim, g_elev, g_dist);
+}
+template <typename T> MVR_HD void look_at_bwd_from_state(const LookAtFwd<T> &fw, T dist, const T gR[9], const T gT[3], T *g_azim, T *g_elev, T *g_dist) {
+  const LookAtState<T> &st = fw.st;
   V3<T> gx = {gR[0], gR[3], gR[6]}, gy = {gR[1], gR[4], gR[7]}, gz = {gR[2], gR[5], gR[8]};
   // T_j = -(axis_j . C)
   V3<T> gC = {-((gT[0] * st.x.x + gT[1] * st.y.x) + gT[2] * st.z.x),
@@ -309,7 +323,11 @@ template <typename T> MVR_HD void look_at_bwd(T azim, T elev, T dist, const T gR
   // z = normalize(-C)
   V3<T> gneg = normalize_bwd(st.z, st.dz, st.cz, gz);
   gC = {gC.x - gneg.x, gC.y - gneg.y, gC.z - gneg.z};
-  camera_position_bwd(azim, elev, dist, gC, g_azim, g_elev, g_dist);
+  // camera_position_bwd with the forward's sines and cosines (the same values: sincos_deg of the same angles)
+  const T se = fw.se, ce = fw.ce, sa = fw.sa, ca = fw.ca, k = (T)(kPi / 180.0);
+  *g_dist = (gC.x * (ce * sa) + gC.y * se) + gC.z * (ce * ca);
+  *g_elev = k * (dist * ((gC.x * (-se * sa) + gC.y * ce) + gC.z * (-se * ca)));
+  *g_azim = k * (dist * (gC.x * (ce * ca) - gC.z * (ce * sa)));
 }
 
 // Camera centre the shader uses: cameras.get_camera_center() = -T R^T.
