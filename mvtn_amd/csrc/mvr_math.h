@@ -854,6 +854,37 @@ template <typename T> MVR_HD SoftFrag<T> soft_frag_eval(const V3<T> &v0, const V
   }
   return f;
 }
+// soft_frag_eval(..., with_dist = false) with its nine IEEE divisions — three each by the face's area, by the perspective
+// denominator and by the clip sum — through div_by and ONE correctly rounded reciprocal per divisor (r_area = RN(1 / area) comes
+// from the caller: it is a per-face constant): the same quotients bit for bit (Markstein: RN(q + (a - b q) y) = RN(a / b) for
+// y = RN(1 / b), q = RN(a y), absent underflow — numerators here are edge values and their products with vertex depths), 51
+// operations instead of 108.  The soft forward's candidate walk is bound by exactly this arithmetic.
+template <typename T> MVR_HD SoftFrag<T> soft_frag_eval_shared(const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, T area, T r_area, T px, T py,
+                                                               bool persp, bool clip_bary) {
+  SoftFrag<T> f;
+  T w0 = div_by(edge_fn(px, py, v1.x, v1.y, v2.x, v2.y), area, r_area);
+  T w1 = div_by(edge_fn(px, py, v2.x, v2.y, v0.x, v0.y), area, r_area);
+  T w2 = div_by(edge_fn(px, py, v0.x, v0.y, v1.x, v1.y), area, r_area);
+  if (persp) {
+    const T t0 = (w0 * v1.z) * v2.z, t1 = (v0.z * w1) * v2.z, t2 = (v0.z * v1.z) * w2;
+    const T den = tmax((t0 + t1) + t2, (T)kEps);
+    const T rden = (T)1 / den;
+    w0 = div_by(t0, den, rden); w1 = div_by(t1, den, rden); w2 = div_by(t2, den, rden);
+  }
+  f.w0 = w0; f.w1 = w1; f.w2 = w2;
+  T c0 = w0, c1 = w1, c2 = w2;
+  if (clip_bary) {   // BarycentricClipForward
+    c0 = tmax(tmin(w0, (T)1), (T)0); c1 = tmax(tmin(w1, (T)1), (T)0); c2 = tmax(tmin(w2, (T)1), (T)0);
+    const T sm = tmax((c0 + c1) + c2, (T)1e-5);
+    const T rsm = (T)1 / sm;
+    c0 = div_by(c0, sm, rsm); c1 = div_by(c1, sm, rsm); c2 = div_by(c2, sm, rsm);
+  }
+  f.b0 = c0; f.b1 = c1; f.b2 = c2;
+  f.z = (c0 * v0.z + c1 * v1.z) + c2 * v2.z;
+  f.inside = w0 > (T)0 && w1 > (T)0 && w2 > (T)0;
+  f.dist = (T)0;
+  return f;
+}
 // the signed squared distance of a fragment evaluated without it (soft_frag_eval(..., with_dist = false))
 template <typename T> MVR_HD void soft_frag_add_dist(SoftFrag<T> *f, const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, T px, T py) {
   const T d = point_triangle_dist2(px, py, v0, v1, v2);
