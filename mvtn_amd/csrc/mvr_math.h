@@ -825,35 +825,6 @@ template <typename T> struct SoftFrag {
   bool inside;
 };
 
-// The fragment of (pixel, face) without the acceptance tests.
-template <typename T> MVR_HD SoftFrag<T> soft_frag_eval(const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, T px, T py, bool persp, bool clip_bary, bool with_dist = true) {
-  SoftFrag<T> f;
-  const T area = edge_fn(v2.x, v2.y, v0.x, v0.y, v1.x, v1.y) + (T)kEps;
-  T w0 = edge_fn(px, py, v1.x, v1.y, v2.x, v2.y) / area;
-  T w1 = edge_fn(px, py, v2.x, v2.y, v0.x, v0.y) / area;
-  T w2 = edge_fn(px, py, v0.x, v0.y, v1.x, v1.y) / area;
-  if (persp) {
-    const T t0 = (w0 * v1.z) * v2.z, t1 = (v0.z * w1) * v2.z, t2 = (v0.z * v1.z) * w2;
-    const T den = tmax((t0 + t1) + t2, (T)kEps);
-    w0 = t0 / den; w1 = t1 / den; w2 = t2 / den;
-  }
-  f.w0 = w0; f.w1 = w1; f.w2 = w2;
-  T c0 = w0, c1 = w1, c2 = w2;
-  if (clip_bary) {   // BarycentricClipForward
-    c0 = tmax(tmin(w0, (T)1), (T)0); c1 = tmax(tmin(w1, (T)1), (T)0); c2 = tmax(tmin(w2, (T)1), (T)0);
-    const T sm = tmax((c0 + c1) + c2, (T)1e-5);
-    c0 = c0 / sm; c1 = c1 / sm; c2 = c2 / sm;
-  }
-  f.b0 = c0; f.b1 = c1; f.b2 = c2;
-  f.z = (c0 * v0.z + c1 * v1.z) + c2 * v2.z;
-  f.inside = w0 > (T)0 && w1 > (T)0 && w2 > (T)0;
-  f.dist = (T)0;
-  if (with_dist) {
-    const T d = point_triangle_dist2(px, py, v0, v1, v2);
-    f.dist = f.inside ? -d : d;
-  }
-  return f;
-}
 // soft_frag_eval(..., with_dist = false) with its nine IEEE divisions — three each by the face's area, by the perspective
 // denominator and by the clip sum — through div_by and ONE correctly rounded reciprocal per divisor (r_area = RN(1 / area) comes
 // from the caller: it is a per-face constant): the same quotients bit for bit (Markstein: RN(q + (a - b q) y) = RN(a / b) for
@@ -883,6 +854,17 @@ template <typename T> MVR_HD SoftFrag<T> soft_frag_eval_shared(const V3<T> &v0, 
   f.z = (c0 * v0.z + c1 * v1.z) + c2 * v2.z;
   f.inside = w0 > (T)0 && w1 > (T)0 && w2 > (T)0;
   f.dist = (T)0;
+  return f;
+}
+// The fragment of (pixel, face) without the acceptance tests (its nine quotients through soft_frag_eval_shared: one IEEE division
+// per divisor — area, perspective denominator, clip sum — instead of three, the same results bit for bit).
+template <typename T> MVR_HD SoftFrag<T> soft_frag_eval(const V3<T> &v0, const V3<T> &v1, const V3<T> &v2, T px, T py, bool persp, bool clip_bary, bool with_dist = true) {
+  const T area = edge_fn(v2.x, v2.y, v0.x, v0.y, v1.x, v1.y) + (T)kEps;
+  SoftFrag<T> f = soft_frag_eval_shared(v0, v1, v2, area, (T)1 / area, px, py, persp, clip_bary);
+  if (with_dist) {
+    const T d = point_triangle_dist2(px, py, v0, v1, v2);
+    f.dist = f.inside ? -d : d;
+  }
   return f;
 }
 // the signed squared distance of a fragment evaluated without it (soft_frag_eval(..., with_dist = false))
