@@ -45,6 +45,10 @@ def parse():
     # final synchronisation) is amortised — 100 steps read 5 % low (120.4 vs 114.3 us per C2 step); still < 1 s of GPU time
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--prewarm", type=int, default=-1,
+                    help="untimed steps run BEFORE the --warmup steps so that clocks, caches and the allocator are warm even when the "
+                         "driver passes a short --warmup; default: what is missing to 300 steps in all (30 for the soft workload); "
+                         "0 = none (then exactly --warmup untimed steps run).  Reported as prewarm_steps in the line.")
     ap.add_argument("--workload", default=None, choices=["mesh_fwd", "mesh_fwdbwd", "points_fwd", "c5", "c5_per_gpu", "soft_fwdbwd"],
                     help="default: mesh_fwd (C2) on one GPU, c5 on several.  c5 = BASELINE configs[4]: 64 ShapeNet-sized (tier L) "
                          "meshes x 20 views in total, sharded over the GPUs, the all-gather inside the step; c5_per_gpu = 8 such "
@@ -289,7 +293,7 @@ def main():
     # (tools/fixed_cost.py: a 20-step region reads 104.5 us / step after 50 steps, 101.6 after 300, 97.6 in steady state).
     # The W warm-up steps proper follow a synchronize of their own: the first launch after a long unsynchronised run pays
     # the HIP runtime's clean-up of the completed commands (200-300 us on this box), which belongs to no step.
-    prewarm = max(0, (30 if soft else 300) - args.warmup)
+    prewarm = max(0, (30 if soft else 300) - args.warmup) if args.prewarm < 0 else args.prewarm
     for _ in range(prewarm):
         out = step()
     barrier()
@@ -329,17 +333,20 @@ def main():
                 "launches_timed": int(cnt[kind])}
     if args.workload == "mesh_fwdbwd" and cnt[4 if soft else 2] > 0:
         roofline["backward_kernel_ms"] = ms[4 if soft else 2] / cnt[4 if soft else 2]
-    # what actually bounds the mesh kernels (profiles/README.md): VALU issue.  A wave64 VALU instruction holds its SIMD for
-    # 4 cycles, so instructions x 4 / 1024 SIMDs is the kernel's VALU floor in cycles; against the LIVE kernel time (at the
-    # 2.07 GHz the counters show under this load) it gives the share of the launch the VALUs were issuing.  The instruction
-    # count comes from the committed SQ counter pass (it is a property of the code and the workload, not of the run).
+    # VALU issue floor of the mesh kernels.  Measured in round 4 (tools/valu_issue.hip -> profiles/r04_a_valu_issue.csv): with
+    # >= 2 waves per SIMD a plain f32 / integer wave64 instruction (v_add / v_mul / v_fma / v_mov / v_and with VGPR operands)
+    # occupies the SIMD for 2 cycles, as /opt/skills/guides/MI355X_MICROARCH.md says — not 4, what rounds 1-3 assumed —, the
+    # packed f32 forms, min / max / med3, DPP moves, integer mad / shift-add, converts and anything with an SGPR operand 3.2,
+    # compares 4, rcp / rsq 6.3.  The floor below prices EVERY instruction at 2 cycles: a lower bound of the issue time; the
+    # kernel's real mix is dearer (cycles_per_instruction_floor names the price used).  Instruction count: the committed SQ
+    # counter pass (a property of the code and the workload, not of the run).
     try:
         import glob
         sqp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.json")))[-1]
         k = json.load(open(sqp)).get(kname)
         if k and k.get("SQ_INSTS_VALU") and kern_ms > 0 and args.workload != "points_fwd" and not c5 and not soft:
-            floor_ms = k["SQ_INSTS_VALU"] * 4.0 / 1024.0 / 2.07e9 * 1e3
-            roofline["valu"] = {"wave_instructions": k["SQ_INSTS_VALU"], "issue_floor_ms": floor_ms, "frac": floor_ms / kern_ms,
+            floor_ms = k["SQ_INSTS_VALU"] * 2.0 / 1024.0 / 2.07e9 * 1e3
+            roofline["valu"] = {"wave_instructions": k["SQ_INSTS_VALU"], "cycles_per_instruction_floor": 2.0, "issue_floor_ms": floor_ms, "frac": floor_ms / kern_ms,
                                 "from_profiles": os.path.relpath(sqp, ROOT)}
     except Exception:
         pass
@@ -499,6 +506,7 @@ def main():
             "metric": "rendered views/sec (224x224 point clouds, 20 views/obj)" if args.workload == "points_fwd" else
                       "rendered views/sec (224x224, %d views/obj)" % V,
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "prewarm_steps": prewarm,   # untimed steps in front of the W warm-up steps (--prewarm): untimed in all = prewarm + W
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if fixed_total else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl,

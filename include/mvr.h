@@ -137,6 +137,10 @@ typedef struct mvr_points_params {
   int32_t reserved2_;     /* explicit padding; must be 0 */
 } mvr_points_params;
 
+/* ABI generation of this header: bumped whenever a struct layout or an entry point's contract changes (101: fov_scale in
+ * mvr_mesh_params, flag 64, 8-entry arrays of mvr_profile_end).  mvr_version() returns the value the library was built with;
+ * a loader must refuse a library whose value differs (mvtn_amd/_lib.py does). */
+#define MVR_ABI_VERSION 101
 int mvr_version(void);
 const char *mvr_last_error(void);
 /* Hash of the sources (and compiler flags) this library was built from, as mvtn_amd/build.py computes it: lets a loader
@@ -230,7 +234,8 @@ size_t mvr_mesh_soft_workspace_bytes(const mvr_mesh_batch *meshes, const mvr_mes
 
 /* images: (N, 4, H, W) RGBA planar (N = B V, n = b V + v; alpha = 1 - prod_k (1 - sigmoid(-dist_k / sigma)));
  * pix_to_face: (N, H, W, K) LOCAL face indices of the K nearest candidate faces per pixel in ascending (z, face) order,
- * -1 = none (required: the backward differentiates exactly these fragments). */
+ * -1 = none (required: the backward differentiates exactly these fragments).  Any 4-byte alignment is accepted; with
+ * faces_per_pixel = 4 a 16-byte aligned array (what every device allocator returns) lets the kernel read a pixel's list in one load. */
 int mvr_render_meshes_soft_forward(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const mvr_soft_params *soft,
                                    const float *R, const float *T, const float *light_dir, float *images, int32_t *pix_to_face,
                                    void *workspace, size_t workspace_bytes, mvr_stream_t stream);

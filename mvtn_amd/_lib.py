@@ -10,6 +10,7 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 _vp = ctypes.c_void_p
 
 MVR_OK = 0
+MVR_ABI_VERSION = 101   # == MVR_ABI_VERSION of include/mvr.h == mvr_version() of the library
 MVR_CULL_BACKFACES = 1
 MVR_PERSPECTIVE_CORRECT = 2
 MVR_WORKSPACE_FROM_FORWARD = 4
@@ -131,13 +132,28 @@ def load():
     if not os.path.exists(path):
         raise ImportError("mvtn_amd: %s does not exist" % path)
     lib = ctypes.CDLL(path)
+    # ABI generation: bumped whenever a struct layout or an entry point's contract changes (include/mvr.h: MVR_ABI_VERSION);
+    # a library of another generation is never used, whoever built it
+    ver_fn = getattr(lib, "mvr_version", None)
+    ver = ver_fn() if ver_fn is not None else -1
+    if ver != MVR_ABI_VERSION:
+        raise ImportError("mvtn_amd: %s has ABI version %d, this package binds version %d (include/mvr.h) — rebuild it with "
+                          "`python -c 'import __graft_entry__ as g; g.build()'`" % (path, ver, MVR_ABI_VERSION))
     if unverified:
-        lib.mvr_source_hash.restype = ctypes.c_char_p
-        have = (lib.mvr_source_hash() or b"").decode()
+        # the library could not be rebuilt here: it must carry the hash of exactly the sources beside it.  A stale library is
+        # refused (struct layouts move between builds) unless the caller opts in with MVR_ALLOW_STALE_LIB=1.
+        hash_fn = getattr(lib, "mvr_source_hash", None)   # (a library that predates mvr_source_hash is stale by definition)
+        have = ""
+        if hash_fn is not None:
+            hash_fn.restype = ctypes.c_char_p
+            have = (hash_fn() or b"").decode()
         if have != _build.source_hash():
+            msg = ("mvtn_amd: %s was built from other sources than the ones beside it (library %s..., tree %s...) and could not be "
+                   "rebuilt here" % (path, have[:12] or "<none>", _build.source_hash()[:12]))
+            if os.environ.get("MVR_ALLOW_STALE_LIB") != "1":
+                raise ImportError(msg + "; set MVR_ALLOW_STALE_LIB=1 to load it anyway")
             import warnings
-            warnings.warn("mvtn_amd: %s was built from other sources than the ones beside it (library %s..., tree %s...) and could "
-                          "not be rebuilt here; loading it as it is" % (path, have[:12], _build.source_hash()[:12]), RuntimeWarning)
+            warnings.warn(msg + "; loading it as it is (MVR_ALLOW_STALE_LIB=1)", RuntimeWarning)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res

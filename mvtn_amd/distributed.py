@@ -66,8 +66,13 @@ def all_gather_views(local_images, counts=None, group=None):
 
 
 def _channels(renderer):
-    """Channels of the renderer's images: the soft shaders return RGBA with `return_alpha` (mvtn_amd/renderer.py)."""
-    return 4 if (getattr(renderer, "return_alpha", False) and getattr(renderer, "shader", "hard_phong") != "hard_phong") else 3
+    """Channels of the renderer's images: MVRenderer.out_channels (RGBA only from the soft MESH shaders with `return_alpha`;
+    the point path and the hard shader return RGB whatever the flag says)."""
+    oc = getattr(renderer, "out_channels", None)
+    if oc is not None:
+        return int(oc)
+    soft_mesh = getattr(renderer, "shader", "hard_phong") != "hard_phong" and not getattr(renderer, "pc_rendering", False)
+    return 4 if (getattr(renderer, "return_alpha", False) and soft_mesh) else 3
 
 
 def _image_tail(renderer, azim, group, have_local, local_tail):

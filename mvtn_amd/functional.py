@@ -126,7 +126,7 @@ def camera_position_from_spherical_angles(distance, elevation, azimuth):
 
 def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backfaces=False, perspective_correct=True,
                 fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, strip_rows=0, exact_raster=False, z_clip=None,
-                gather_backward=False, normalize=None, fov_scale=0.0, normals_three_cross=False):
+                gather_backward=False, normalize=None, fov_scale=0.0, normals_three_cross=True):
     """`exact_raster`: skip the fast rasteriser (MVR_RASTER_EXACT_ONLY); the images are the same either way.
     `gather_backward`: skip the face-table backward kernel (MVR_BACKWARD_GATHER); same gradients up to summation order.
     `normalize`: (mean, std) per channel (or scalars): the trainer's Normalize, (rgb - mean) / std, applied in the
@@ -134,8 +134,9 @@ def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backface
     `z_clip`: view depth of PyTorch3D >= 0.5's face clipping; None = the reference's rule (znear / 2 = 0.5 when
     perspective_correct — MeshRasterizer only clips for perspective cameras with it on —, else off); 0 = off.
     `fov_scale`: 0 = the projection scale from `fov` (1 / tan(fov / 2) evaluated in double, rounded once); > 0: used as given
-    (K[0][0] of a particular PyTorch3D build).  `normals_three_cross`: the vertex normals from three cross products per
-    face (MVR_NORMALS_THREE_CROSS) instead of one — the two forms of Meshes._compute_vertex_normals."""
+    (K[0][0] of a particular PyTorch3D build).  `normals_three_cross` (default): the vertex normals from three cross products per
+    face (MVR_NORMALS_THREE_CROSS: Meshes._compute_vertex_normals of the PyTorch3D releases of the reference's era); False: one
+    cross product per face added to its three vertices (the later form).  ~1e-7 apart, colours only."""
     if z_clip is None:
         z_clip = 0.5 if perspective_correct else 0.0
     H, W = (image_size, image_size) if isinstance(image_size, int) else image_size

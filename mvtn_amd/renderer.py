@@ -59,10 +59,11 @@ class MVRenderer(nn.Module):
                  faces_per_pixel=1, points_radius=0.006, points_per_pixel=1, light_direction="random",
                  cull_backfaces=False, *, perspective_correct=True, rotation_check="device", strip_rows=0, z_clip=None,
                  shader="hard_phong", blur_radius=0.0, sigma=1e-4, gamma=1e-4, return_alpha=False, normalize=None,
-                 fov_scale=0.0, normals_three_cross=False):
+                 fov_scale=0.0, normals_three_cross=True):
         super().__init__()
         # the two places where a PyTorch3D build may differ from the defaults in the last bit (functional.mesh_params):
-        # fov_scale > 0 = that build's K[0][0]; normals_three_cross = vertex normals from three cross products per face
+        # fov_scale > 0 = that build's K[0][0]; normals_three_cross (default) = vertex normals from three cross products per face,
+        # PyTorch3D's form in the reference's era; False = one cross product per face (the later form)
         self.fov_scale, self.normals_three_cross = float(fov_scale), bool(normals_three_cross)
         # normalize=(mean, std): the trainer's Normalize (viewGCN/tools/Trainer_mvt.py:41-49) applied in the mesh rasteriser's
         # stores — the images come out as (rgb - mean) / std, differentiably, with no pass over the frames afterwards
@@ -160,6 +161,12 @@ class MVRenderer(nn.Module):
             st = self._st
             st.pending = [h for h in st.pending if h is not host]
             st.pool.append(host)
+
+    @property
+    def out_channels(self):
+        """Channels of the images forward() returns: 4 (RGBA) only from the soft MESH shaders with `return_alpha`; the point
+        path and the hard shader return RGB (mvtn_amd.distributed sizes the tail of an empty shard with it)."""
+        return 4 if (self.return_alpha and self.shader != "hard_phong" and not self.pc_rendering) else 3
 
     def check_status(self, block=True):
         """Raise the reference's sys.exit("Remedy did not work") if an earlier forward exhausted the

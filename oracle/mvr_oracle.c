@@ -16,42 +16,55 @@ static int orc_threads = 1;
 void orc_set_threads(int n) { orc_threads = n > 1 ? n : 1; }
 
 /* Switches for the two places where upstream's op order / precision is uncertain (Weak 1; RECALLED semantics):
- *   normals_three_cross: 0 (default) = ONE cross(v2 - v1, v0 - v1) per face added to its three vertices (what
- *       Meshes._compute_vertex_normals does in 0.6+ as this restatement recalls it); 1 = three different cross products,
- *       (v2-v1)x(v0-v1) -> vertex 1, (v0-v2)x(v1-v2) -> vertex 2, (v1-v0)x(v2-v0) -> vertex 0, in that order (the form the
- *       round-2 review recalls).  Equal in exact arithmetic, ~1e-7 apart in fp32.
+ *   normals_three_cross: 1 (default since round 4) = three different cross products per face, (v2-v1)x(v0-v1) -> vertex 1,
+ *       (v0-v2)x(v1-v2) -> vertex 2, (v1-v0)x(v2-v0) -> vertex 0, in that order: Meshes._compute_vertex_normals of the
+ *       PyTorch3D releases of the reference's era (its README pins pytorch 1.7.1 -> PyTorch3D 0.3 / 0.4; both reviews recall this
+ *       form for 0.2 - 0.7); 0 = ONE cross(v2 - v1, v0 - v1) per face added to its three vertices (the later form).
+ *       Equal in exact arithmetic, ~1e-7 apart in fp32 (colours only, never coverage).
  *   fov_scale_override: 0 (default) = s = RN(1 / tan(fov / 2)) evaluated in double; > 0: used as s as given — a PyTorch3D
  *       build computes K[0][0] from an fp32 torch.tan whose last bit depends on the device's tan (torch CPU here:
  *       0x1.bb67b0p+0, this restatement: 0x1.bb67aep+0, numpy's tanf: 0x1.bb67acp+0 for fov = 60). */
-static int orc_normals_three_cross = 0;
+static int orc_normals_three_cross = 1;
 static double orc_fov_scale_override = 0.0;
+/*   edge_fma (round 4, VERDICT r3 missing 1b): 0 (default) = the per-pixel test as the plain IEEE sequence of PyTorch3D's C++ source
+ *       (what its CPU rasteriser executes with contraction off); 1 = the same expressions CONTRACTED the way nvcc (-fmad=true,
+ *       the default) compiles them for the CUDA kernels the reference actually runs (models/renderer.py:67-68,77,85 hard-code
+ *       .cuda()): a b - c d -> fma(a, b, -RN(c d)) in EdgeFunctionForward, the sum of the perspective-correction numerators and
+ *       the interpolated depth as chains of FMAs (the first product of every sum is rounded, the later ones fused).  One
+ *       plausible contraction, not a disassembly: it measures how many pixels such a difference can move. */
+static int orc_edge_fma = 0;
 void orc_set_options(int normals_three_cross, double fov_scale_override) {
   orc_normals_three_cross = normals_three_cross ? 1 : 0;
   orc_fov_scale_override = fov_scale_override > 0.0 ? fov_scale_override : 0.0;
 }
+void orc_set_edge_fma(int on) { orc_edge_fma = on ? 1 : 0; }
 
 #define REAL float
 #define SUFFIX _f32
 #define SQRT_FN sqrtf
 #define FABS_FN fabsf
 #define POW_FN powf
+#define FMA_FN fmaf
 #include "mvr_oracle_impl.inc"
 #undef REAL
 #undef SUFFIX
 #undef SQRT_FN
 #undef FABS_FN
 #undef POW_FN
+#undef FMA_FN
 
 #define REAL double
 #define SUFFIX _f64
 #define SQRT_FN sqrt
 #define FABS_FN fabs
 #define POW_FN pow
+#define FMA_FN fma
 #include "mvr_oracle_impl.inc"
 #undef REAL
 #undef SUFFIX
 #undef SQRT_FN
 #undef FABS_FN
 #undef POW_FN
+#undef FMA_FN
 
 int orc_version(void) { return 1; }

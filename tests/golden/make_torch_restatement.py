@@ -89,12 +89,14 @@ def fov_projection_matrix(N, fov_deg=60.0, znear=1.0, zfar=100.0, aspect=1.0):
 
 
 def verts_normals(verts, faces):
+    """Meshes._compute_vertex_normals as in the PyTorch3D releases of the reference's era (its README pins pytorch 1.7.1, i.e.
+    PyTorch3D 0.3 / 0.4; the form recalled for 0.2 - 0.7): THREE cross products per face, index_add'ed to vertices 1, 2, 0 in
+    that order.  (Rounds 2-3 generated the fixtures with the later one-cross form; colours differ by ~2e-6, coverage never.)"""
     vf = verts[faces]
-    fn = torch.cross(vf[:, 2] - vf[:, 1], vf[:, 0] - vf[:, 1], dim=1)
     n = torch.zeros_like(verts)
-    n = n.index_add(0, faces[:, 0], fn)
-    n = n.index_add(0, faces[:, 1], fn)
-    n = n.index_add(0, faces[:, 2], fn)
+    n = n.index_add(0, faces[:, 1], torch.cross(vf[:, 2] - vf[:, 1], vf[:, 0] - vf[:, 1], dim=1))
+    n = n.index_add(0, faces[:, 2], torch.cross(vf[:, 0] - vf[:, 2], vf[:, 1] - vf[:, 2], dim=1))
+    n = n.index_add(0, faces[:, 0], torch.cross(vf[:, 1] - vf[:, 0], vf[:, 2] - vf[:, 0], dim=1))
     return F.normalize(n, eps=1e-6, dim=1)
 
 

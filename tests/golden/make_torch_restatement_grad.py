@@ -1,0 +1,165 @@
+"""Generates tests/golden/torch_restatement_grad.npz: a SECOND implementation of the mesh path's BACKWARD (missing 1a).
+
+Every gradient test of rounds 1-3 differentiated the builder's own C oracle by finite differences.  Here the forward of
+make_torch_restatement.py (real fp32 torch ops in PyTorch3D's op order: look-at, 4 x 4 bmm transforms + homogeneous divide,
+three-cross vertex normals, phong_shading, hard blend) is re-run DIFFERENTIABLY: the pixel -> face map comes from the naive
+rasteriser under no_grad and is then held fixed, exactly as PyTorch3D's rasteriser treats it (no gradient through indices,
+run_mvtn.py:195 only ever sees d colour / d barycentrics); the perspective-corrected barycentrics of each pixel's winning
+face are recomputed from the projected vertices with the forward's operations as differentiable torch ops, the Phong
+shading and the camera centre (torch.inverse of the world-to-view matrix) likewise, and `loss.backward()` through
+torch.autograd gives d loss / d (azim, elev, dist).  loss = sum(G * images) with G = standard normal, seeded.
+
+Two cases:
+  c1   BASELINE configs[0]: one tier-M mesh, 4 circular views, 128 x 128, light_direction "fixed" (0, 1, 0);
+  c3   two objects of BASELINE configs[2]: tier M (seeds 0, 1), 12 jittered spherical views each, 224 x 224,
+       light_direction "relative" (the light is the camera position, models/renderer.py:167-171: a third gradient path).
+
+What it pins: the analytic backward kernels (k_mesh_backward_tab, k_mesh_backward) and the oracle's finite differences
+against torch.autograd through a second reading of the same semantics.  What it cannot pin: PyTorch3D itself (not
+installable here) — "parity unpinned" stays.
+
+    python tests/golden/make_torch_restatement_grad.py [c1] [c3]        (CPU; c1 ~1 min, c3 ~15 min)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from mvtn_amd import synthetic as syn  # noqa: E402
+import make_torch_restatement as r1  # noqa: E402
+
+KEPS = r1.KEPS
+
+
+def pix_centres(S):
+    idx = torch.arange(S, dtype=torch.float32)
+    c = -1.0 + (2.0 * idx + 1.0) / S
+    py = c.flip(0)[:, None].expand(S, S)
+    px = c.flip(0)[None, :].expand(S, S)
+    return px, py
+
+
+def bary_of_winners(ndc, faces, p2f):
+    """BarycentricCoordsForward + BarycentricPerspectiveCorrectionForward of the winning face of every pixel, as
+    differentiable torch ops on the projected vertices (S, S, 3); background pixels get the face 0 (masked later)."""
+    S = p2f.shape[0]
+    px, py = pix_centres(S)
+    fv = ndc[faces][p2f.clamp(min=0)]                                 # (S, S, 3 corners, 3)
+    v0, v1, v2 = fv[..., 0, :], fv[..., 1, :], fv[..., 2, :]
+    area = r1.edge(v2[..., 0], v2[..., 1], v0[..., 0], v0[..., 1], v1[..., 0], v1[..., 1]) + KEPS
+    w0 = r1.edge(px, py, v1[..., 0], v1[..., 1], v2[..., 0], v2[..., 1]) / area
+    w1 = r1.edge(px, py, v2[..., 0], v2[..., 1], v0[..., 0], v0[..., 1]) / area
+    w2 = r1.edge(px, py, v0[..., 0], v0[..., 1], v1[..., 0], v1[..., 1]) / area
+    t0 = w0 * v1[..., 2] * v2[..., 2]
+    t1 = v0[..., 2] * w1 * v2[..., 2]
+    t2 = v0[..., 2] * v1[..., 2] * w2
+    den = torch.clamp(t0 + t1 + t2, min=KEPS)
+    return torch.stack([t0 / den, t1 / den, t2 / den], dim=-1)
+
+
+def phong_diff(p2f, bary, verts, faces, normals, cam_center, light_dir, obj, bg):
+    """r1.phong with a light direction that may be a tensor carrying a gradient (the "relative" light)."""
+    S = p2f.shape[0]
+    mask = p2f >= 0
+    f = p2f.clamp(min=0)
+    fverts, fnorm = verts[faces][f], normals[faces][f]
+    fcol = torch.tensor(obj)[None, None, None, :].expand(S, S, 3, 3)
+    pixel_coords = (bary[..., None] * fverts).sum(dim=-2)
+    pixel_normals = (bary[..., None] * fnorm).sum(dim=-2)
+    texels = (bary[..., None] * fcol).sum(dim=-2)
+    nrm = F.normalize(pixel_normals, p=2, dim=-1, eps=1e-6)
+    direction = F.normalize(light_dir[None, None, :].expand(S, S, 3), p=2, dim=-1, eps=1e-6)
+    cos_angle = torch.sum(nrm * direction, dim=-1)
+    diffuse = torch.tensor([0.3, 0.3, 0.3]) * F.relu(cos_angle)[..., None]
+    lit = (cos_angle > 0).to(torch.float32)
+    view_direction = F.normalize(cam_center[None, None, :] - pixel_coords, p=2, dim=-1, eps=1e-6)
+    reflect = -direction + 2 * (cos_angle[..., None] * nrm)
+    alpha = F.relu(torch.sum(view_direction * reflect, dim=-1)) * lit
+    specular = torch.tensor([0.2, 0.2, 0.2]) * torch.pow(alpha, 64.0)[..., None]
+    ambient = torch.tensor([1.0, 1.0, 1.0]) * torch.tensor([0.5, 0.5, 0.5])
+    colors = (ambient + diffuse) * texels + specular
+    out = torch.where(mask[..., None], colors, torch.tensor(bg)[None, None, :])
+    return out.permute(2, 0, 1)
+
+
+def render_views_diff(verts, faces, az, el, di, S, relative_light, g_seed):
+    """One mesh, V views: images with the pixel -> face map fixed, loss = sum(G * images), gradients by autograd."""
+    V = len(az)
+    a, e, d = (torch.from_numpy(np.asarray(x, np.float32)).clone().requires_grad_(True) for x in (az, el, di))
+    R, T = r1.look_at_view_transform(d, e, a)
+    W2V = r1.world_to_view_matrix(R, T)
+    K = r1.fov_projection_matrix(V)
+    view = r1.transform_points(verts[None].expand(V, -1, -1), W2V)
+    ndc_xy = r1.transform_points(view, K)
+    ndc = torch.cat([ndc_xy[..., :2], view[..., 2:3]], dim=-1)       # the rasteriser keeps the view depth
+    nrm = r1.verts_normals(verts, faces)
+    centers = torch.inverse(W2V)[:, 3, :3]
+    lights = r1.camera_position_from_spherical_angles(d, e, a) if relative_light else None
+    obj = bg = (0.99999, 0.99999, 0.99999)
+    G = torch.from_numpy(np.random.default_rng(g_seed).standard_normal((V, 3, S, S)).astype(np.float32))
+    loss = torch.zeros(())
+    p2f_all, img_all = [], []
+    for n in range(V):
+        with torch.no_grad():
+            p2f, _, _ = r1.rasterize(ndc[n].detach(), faces, S)
+        bary = bary_of_winners(ndc[n], faces, p2f)
+        light = lights[n] if relative_light else torch.tensor([0.0, 1.0, 0.0])
+        img = phong_diff(p2f, bary, verts, faces, nrm, centers[n], light, obj, bg)
+        loss = loss + (img * G[n]).sum()
+        p2f_all.append(p2f)
+        img_all.append(img.detach())
+        print("  view", n, "covered", float((p2f >= 0).float().mean()), flush=True)
+    loss.backward()
+    return (torch.stack(p2f_all).numpy().astype(np.int16), torch.stack(img_all).numpy(),
+            a.grad.numpy().copy(), e.grad.numpy().copy(), d.grad.numpy().copy())
+
+
+def c3_views(B, V, seed):
+    """The jittered views of bench.py / the GPU tests for configs[2]: grid + U(-5, 5) degrees, U(-0.1, 0.1) distance."""
+    az, el, di = syn.spherical_views(V)
+    rng = np.random.default_rng(seed)
+    az = np.tile(az, (B, 1)) + rng.uniform(-5, 5, (B, V))
+    el = np.tile(el, (B, 1)) + rng.uniform(-5, 5, (B, V))
+    di = np.tile(di, (B, 1)) + rng.uniform(-0.1, 0.1, (B, V))
+    return az.astype(np.float32), el.astype(np.float32), di.astype(np.float32)
+
+
+def main(which):
+    torch.set_num_threads(8)
+    out = {}
+    if "c1" in which:
+        v, f = syn.synthetic_mesh("M", 0)
+        az, el, di = syn.circular_views(4, 30.0, 2.2)
+        p2f, img, ga, ge, gd = render_views_diff(torch.from_numpy(v), torch.from_numpy(f), az, el, di, 128, False, 101)
+        out.update(c1_azim=az, c1_elev=el, c1_dist=di, c1_pix_to_face=p2f, c1_grad_azim=ga, c1_grad_elev=ge, c1_grad_dist=gd,
+                   c1_g_seed=np.array(101), c1_image_size=np.array(128), c1_image_sum=np.array(img.astype(np.float64).sum()))
+        print("c1 grads", ga, ge, gd)
+    if "c3" in which:
+        B, V, S = 2, 12, 224
+        az, el, di = c3_views(B, V, 1)
+        p2fs, gas, ges, gds, sums = [], [], [], [], []
+        for b in range(B):
+            v, f = syn.synthetic_mesh("M", b)
+            p2f, img, ga, ge, gd = render_views_diff(torch.from_numpy(v), torch.from_numpy(f), az[b], el[b], di[b], S, True, 200 + b)
+            p2fs.append(p2f); gas.append(ga); ges.append(ge); gds.append(gd); sums.append(img.astype(np.float64).sum())
+        out.update(c3_azim=az, c3_elev=el, c3_dist=di, c3_pix_to_face=np.stack(p2fs), c3_grad_azim=np.stack(gas),
+                   c3_grad_elev=np.stack(ges), c3_grad_dist=np.stack(gds), c3_g_seeds=np.array([200, 201]), c3_image_size=np.array(S),
+                   c3_mesh_seeds=np.array([0, 1]), c3_image_sum=np.array(sums))
+        print("c3 grads", np.stack(gas), np.stack(ges), np.stack(gds))
+    path = os.path.join(HERE, "torch_restatement_grad.npz")
+    if os.path.exists(path):   # a partial run keeps the other case
+        old = dict(np.load(path))
+        old.update(out)
+        out = old
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or ["c1", "c3"])

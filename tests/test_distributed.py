@@ -238,3 +238,20 @@ def test_packed_shard_must_match():
         _local_meshes(p, 0, 4, 8, 2)
     assert _local_meshes(["a", "b", "c", "d"], 1, 3, 4, 2) == ["b", "c"]
     assert _local_meshes(None, 0, 1, 2, 2) is None
+
+
+def test_empty_shard_tail_channels_follow_the_renderer():
+    """RGBA only from the soft MESH shaders with return_alpha; a point-cloud renderer constructed with
+    shader="soft_phong", return_alpha=True still returns 3 channels, and so must the tail of an empty shard."""
+    from mvtn_amd import MVRenderer
+    from mvtn_amd.distributed import _channels
+    assert _channels(MVRenderer(4, 32, pc_rendering=False, shader="soft_phong", return_alpha=True)) == 4
+    assert _channels(MVRenderer(4, 32, pc_rendering=True, shader="soft_phong", return_alpha=True)) == 3
+    assert _channels(MVRenderer(4, 32, pc_rendering=False, shader="hard_phong", return_alpha=True)) == 3
+    assert _channels(MVRenderer(4, 32, pc_rendering=False, shader="soft_silhouette")) == 3
+
+    class Stand:   # a stand-in without out_channels: the attribute rule
+        shader, return_alpha, pc_rendering = "soft_phong", True, True
+    assert _channels(Stand()) == 3
+    Stand.pc_rendering = False
+    assert _channels(Stand()) == 4

@@ -141,7 +141,7 @@ def test_hip_point_path_against_the_torch_restatement(K):
     idx = idx.cpu().numpy().reshape(40, S, S, K)
     want = fx["idx_k%d" % K].astype(np.int32)
     differ = (idx != want).any(-1)
-    assert differ.sum() <= 8, "slot lists differ at %d pixels" % differ.sum()
+    assert differ.sum() == 0, "slot lists differ at %d pixels" % differ.sum()   # (observed: 0 of 2 007 040 / 8 028 160 slots)
     diff = np.abs(img.cpu().numpy() - fx["images_k%d" % K]).max(2).reshape(differ.shape)
     big = diff > 1e-6
     print("K=%d: slot lists differ at %d pixels; %d pixels above 1e-6 (clamp region), max %.3g" % (K, differ.sum(), big.sum(), diff.max()))
@@ -151,7 +151,7 @@ def test_hip_point_path_against_the_torch_restatement(K):
 
 def test_hip_face_clipping_against_the_torch_restatement():
     """clip_faces / convert_clipped_rasterization_to_original_faces as torch ops (dist 1.1: 65 and 63 faces cut) vs the HIP
-    path: same counts of cut faces, pixel -> face identical up to a handful of pixels, colours within 1e-4."""
+    path: same counts of cut faces, pixel -> face identical at every pixel, colours within 1e-4."""
     from mvtn_amd import Meshes, functional as F
     from mvtn_amd.structures import PackedMeshes
     fx = _fx("torch_restatement_zclip.npz")
@@ -164,7 +164,7 @@ def test_hip_face_clipping_against_the_torch_restatement():
         img, p2f, n_st = F.render_meshes_fragments(packed, R, T, _t(np.array([[0.0, 1.0, 0.0]], np.float32)), params, return_straddlers=True)
         assert int(n_st) == int(fx["straddlers"].sum())
         differ = p2f.cpu().numpy() != fx["pix_to_face"].astype(np.int32)
-        assert differ.sum() <= 8, differ.sum()
+        assert differ.sum() == 0, differ.sum()   # (observed: 0 of 32 768 pixels)
         assert np.abs(img.cpu().numpy()[0] - fx["images"]).max(1)[~differ].max() <= TOL_PIXEL
 
 
@@ -182,7 +182,7 @@ def test_hip_soft_phong_against_the_torch_restatement():
     soft = F.soft_params(float(fx["blur_radius"]), K, "soft_phong", float(fx["sigma"]), float(fx["gamma"]))
     img, p2f = F.render_meshes_soft(packed, R, T, _t([[0.0, 1.0, 0.0]]), params, soft, return_fragments=True)
     differ = (p2f.cpu().numpy().reshape(V, S, S, K) != fx["pix_to_face"].astype(np.int32)).any(-1)
-    assert differ.sum() <= 8, differ.sum()
+    assert differ.sum() == 0, differ.sum()   # (observed: 0 of 32 768 fragment slots)
     diff = np.abs(img.cpu().numpy().reshape(V, 4, S, S) - fx["images"]).max(1)
     assert diff[~differ].max() <= TOL_PIXEL
 
@@ -197,12 +197,12 @@ def test_library_switches_follow_the_oracle_switches(oracle):
     s1 = float.fromhex("0x1.bb67b0p+0")
     kw = dict(obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
     outs = {}
-    for name, three, s in (("default", False, 0.0), ("three_cross", True, 0.0), ("fov_scale", False, s1)):
+    for name, three, s in (("default", True, 0.0), ("one_cross", False, 0.0), ("fov_scale", True, s1)):
         try:
             oracle.set_options(three, s)
             want = oracle.render_meshes([v], [f], az, el, di, size, **kw)
         finally:
-            oracle.set_options(False, 0.0)
+            oracle.set_options()
         r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="fixed",
                        fov_scale=s, normals_three_cross=three).eval()
         a, e, d = (_t(x).requires_grad_(True) for x in (az, el, di))
@@ -212,10 +212,10 @@ def test_library_switches_follow_the_oracle_switches(oracle):
         img.sum().backward()
         assert torch.isfinite(a.grad).all() and float(a.grad.abs().max()) > 0
         outs[name] = (img.detach().cpu().numpy(), want["images"])
-    assert 0 < np.abs(outs["three_cross"][0] - outs["default"][0]).max() < 1e-5      # normals: colours move in the 7th digit
+    assert 0 < np.abs(outs["one_cross"][0] - outs["default"][0]).max() < 1e-5      # normals: colours move in the 7th digit
     assert np.abs(outs["fov_scale"][0] - outs["default"][0]).max() > 0                # s one ulp larger: the image changes
     # the HIP path follows the oracle THROUGH the switch (not merely both within tolerance of the default)
-    d_hip, d_orc = outs["three_cross"][0] - outs["default"][0], outs["three_cross"][1] - outs["default"][1]
+    d_hip, d_orc = outs["one_cross"][0] - outs["default"][0], outs["one_cross"][1] - outs["default"][1]
     assert np.abs(d_hip - d_orc).max() < 5e-6
 
 

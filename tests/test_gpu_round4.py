@@ -1,0 +1,83 @@
+"""-m gpu, round 4: the HIP backward kernels against torch.autograd through the second, torch-made implementation
+(tests/golden/make_torch_restatement_grad.py -> torch_restatement_grad.npz; VERDICT r3 missing 1a)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mvtn_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test needs a GPU"
+    return torch.device("cuda:0")
+
+
+def _t(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(_dev())
+
+
+def _fx(name):
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
+def _hip_grads(vl, fl, az, el, di, S, G, relative_light, gather):
+    """d sum(G * images) / d (azim, elev, dist) from the HIP path (one autograd node per direction), (B, V) each; and the
+    pixel -> face maps of the same forward."""
+    from mvtn_amd import Meshes, functional as F
+    from mvtn_amd.structures import PackedMeshes
+    B, V = az.shape
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    a, e, d = (_t(x.reshape(-1)).requires_grad_(True) for x in (az, el, di))
+    light = None if relative_light else _t([[0.0, 1.0, 0.0]])
+    params = F.mesh_params(V, S, B * V if relative_light else 1, (0.99999,) * 3, (0.99999,) * 3, gather_backward=gather)
+    images, R, T, _ = F.render_mesh_views(packed, a, e, d, light, params)
+    (images * _t(G).reshape(images.shape)).sum().backward()
+    with torch.no_grad():
+        lt = F.camera_position_from_spherical_angles(d, e, a) if relative_light else light
+        _, p2f = F.render_meshes_fragments(packed, R.detach(), T.detach(), lt.detach(), params)
+    return [x.grad.cpu().numpy().reshape(B, V).astype(np.float64) for x in (a, e, d)], p2f.cpu().numpy()
+
+
+@pytest.mark.parametrize("gather", [False, True], ids=["table_kernel", "gather_kernel"])
+def test_backward_kernels_against_torch_autograd_c1(gather):
+    """BASELINE configs[0] (tier M, 4 circular views, 128 x 128, fixed light): both backward kernels against
+    torch.autograd through the torch restatement with the pixel -> face map held fixed; rel <= 2e-3 asked, ~1e-5 seen."""
+    fx = _fx("torch_restatement_grad.npz")
+    v, f = syn.synthetic_mesh("M", 0)
+    S = int(fx["c1_image_size"])
+    az, el, di = (fx["c1_" + k][None].astype(np.float32) for k in ("azim", "elev", "dist"))
+    G = np.random.default_rng(int(fx["c1_g_seed"])).standard_normal((1, 4, 3, S, S)).astype(np.float32)
+    grads, p2f = _hip_grads([v], [f], az, el, di, S, G, False, gather)
+    assert (p2f != fx["c1_pix_to_face"].astype(np.int32)).sum() == 0      # the same function is being differentiated
+    for name, got in zip(("azim", "elev", "dist"), grads):
+        ref = fx["c1_grad_" + name].astype(np.float64)[None]
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        print("c1 %s (%s): max relative error %.2e" % (name, "gather" if gather else "table", rel))
+        assert rel <= 2e-4, (name, got, ref)
+
+
+@pytest.mark.parametrize("gather", [False, True], ids=["table_kernel", "gather_kernel"])
+def test_backward_kernels_against_torch_autograd_c3(gather):
+    """Two objects of BASELINE configs[2] (tier M, 12 jittered views each, 224 x 224, RELATIVE light: the gradient also
+    flows through the light direction = camera position, models/renderer.py:167-171) against torch.autograd."""
+    fx = _fx("torch_restatement_grad.npz")
+    if "c3_grad_azim" not in fx:
+        pytest.skip("fixture without the c3 case")
+    S = int(fx["c3_image_size"])
+    az, el, di = (fx["c3_" + k].astype(np.float32) for k in ("azim", "elev", "dist"))
+    vl, fl = zip(*[syn.synthetic_mesh("M", int(s)) for s in fx["c3_mesh_seeds"]])
+    G = np.stack([np.random.default_rng(int(s)).standard_normal((12, 3, S, S)).astype(np.float32) for s in fx["c3_g_seeds"]])
+    grads, p2f = _hip_grads(list(vl), list(fl), az, el, di, S, G, True, gather)
+    differ = p2f.reshape(2, 12, S, S) != fx["c3_pix_to_face"].astype(np.int32)
+    # (the torch rasteriser works on bmm-projected vertices: a last-bit difference of a vertex may move an edge pixel; a pixel
+    # that changes face changes the function by one pixel's worth, far below the tolerance)
+    assert differ.sum() <= 8, differ.sum()
+    for name, got in zip(("azim", "elev", "dist"), grads):
+        ref = fx["c3_grad_" + name].astype(np.float64)
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        print("c3 %s (%s): max relative error %.2e over 24 views, %d pixels on another face" % (name, "gather" if gather else "table", rel, differ.sum()))
+        assert rel <= 2e-3, (name, rel)

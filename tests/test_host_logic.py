@@ -107,7 +107,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libmvr_hip.so does not export %s" % name
     assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
-    assert lib.mvr_version() >= 100
+    assert lib.mvr_version() == _lib.MVR_ABI_VERSION == 101
     # struct layouts agree with the header (sizes computed by hand from include/mvr.h)
     assert ctypes.sizeof(_lib.MeshBatch) == 6 * 4 + 5 * 8
     assert ctypes.sizeof(_lib.MeshParams) == 6 * 4 + 5 * 4 + 6 * 4 + 4 + 6 * 4 + 4 * 8 + 8
@@ -414,3 +414,30 @@ def test_renderer_bookkeeping_is_not_module_state():
     assert r._st.calls == 0 and r._st.pending == [] and r._st.pool == []
     r.check_status()   # nothing pending: returns
     assert r.state_dict() == {}
+
+
+def test_stale_library_is_refused_unless_opted_in(monkeypatch):
+    """A library that cannot be rebuilt here and was built from other sources is refused (struct layouts move
+    between builds); MVR_ALLOW_STALE_LIB=1 loads it with a warning; another ABI generation is refused either way."""
+    import warnings
+    from mvtn_amd import _lib, build as b
+    real = _lib.load()
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.delenv("MVR_LIB", raising=False)
+    monkeypatch.setattr(b, "is_current", lambda lib=None: False)
+    monkeypatch.setattr(b, "build_hip", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no hipcc here")))
+    monkeypatch.setattr(b, "source_hash", lambda: "0" * 64)
+    monkeypatch.delenv("MVR_ALLOW_STALE_LIB", raising=False)
+    with pytest.raises(ImportError, match="MVR_ALLOW_STALE_LIB"):
+        _lib.load()
+    monkeypatch.setenv("MVR_ALLOW_STALE_LIB", "1")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert _lib.load() is not None
+    assert any("other sources" in str(x.message) for x in w)
+    # an ABI generation this package does not bind: refused even with the opt-in
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "MVR_ABI_VERSION", 9999)
+    with pytest.raises(ImportError, match="ABI version"):
+        _lib.load()
+    monkeypatch.setattr(_lib, "_LIB", real)

@@ -356,7 +356,7 @@ def test_oracle_against_the_torch_restatement_of_c1(oracle):
     assert np.abs(out["R"] - fx["R"]).max() <= 2.5e-7 and np.abs(out["T"] - fx["T"]).max() <= 5e-7
     p, q = fx["pix_to_face"].astype(np.int32), out["pix_to_face"]
     differ = p != q
-    assert differ.sum() <= 8, "pixel -> face maps of the two implementations differ at %d pixels" % differ.sum()
+    assert differ.sum() == 0, "pixel -> face maps of the two implementations differ at %d pixels" % differ.sum()
     assert abs((q >= 0).mean() - (p >= 0).mean()) < 1e-3 and (q >= 0).mean() > 0.35
     diff = np.abs(out["images"][0] - fx["images"]).max(1)
     assert diff[~differ].max() <= 1e-5
@@ -392,7 +392,7 @@ def test_oracle_against_the_torch_restatement_of_the_point_path(oracle):
         idx = out["idx"] if K > 1 else out["idx"][..., None]
         want = fx["idx_k%d" % K].astype(np.int32)
         differ = (idx != want).any(-1)
-        assert differ.sum() <= 8, "slot lists differ at %d pixels" % differ.sum()
+        assert differ.sum() == 0, "slot lists differ at %d pixels" % differ.sum()
         assert 0.04 < (want[..., 0] >= 0).mean() < 0.07
         d2 = out["dist2"] if K > 1 else out["dist2"][..., None]
         wsum = np.where(idx >= 0, 1.0 - d2.astype(np.float64) / (r * r), 0.0).sum(-1)
@@ -414,7 +414,7 @@ def test_oracle_against_the_torch_restatement_of_face_clipping(oracle):
                                bg_color=(0.99999,) * 3, z_clip=float(fx["z_clip"]))
     assert np.array_equal(out["straddlers"], fx["straddlers"]) and fx["straddlers"].min() > 20
     differ = out["pix_to_face"] != fx["pix_to_face"].astype(np.int32)
-    assert differ.sum() <= 8, "pixel -> face maps differ at %d pixels" % differ.sum()
+    assert differ.sum() == 0, "pixel -> face maps differ at %d pixels" % differ.sum()
     diff = np.abs(out["images"][0] - fx["images"]).max(1)
     assert diff[~differ].max() <= 1e-5
     # and the plane matters: without it the frames are different pictures
@@ -435,7 +435,7 @@ def test_oracle_against_the_torch_restatement_of_the_soft_phong_blend(oracle):
                                     sigma=float(fx["sigma"]), gamma=float(fx["gamma"]), obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
     want = fx["pix_to_face"].astype(np.int32)
     differ = (out["pix_to_face"] != want).any(-1)
-    assert differ.sum() <= 8, "fragment lists differ at %d pixels" % differ.sum()
+    assert differ.sum() == 0, "fragment lists differ at %d pixels" % differ.sum()
     assert (want[..., K - 1] >= 0).mean() > 0.3      # most covered pixels hold K fragments: the blend is exercised
     diff = np.abs(out["images"][0] - fx["images"]).max(1)
     assert diff[~differ].max() <= 1e-4
@@ -452,13 +452,13 @@ def test_oracle_switches_move_colours_only_slightly(oracle):
     kw = dict(obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
     base = oracle.render_meshes([v], [f], az[None], el[None], di[None], 96, **kw)
     try:
-        oracle.set_options(True, 0.0)
+        oracle.set_options(False, 0.0)   # the OTHER form of the normals (one cross product per face)
         n3 = oracle.render_meshes([v], [f], az[None], el[None], di[None], 96, **kw)
         nrm_a = oracle.vertex_normals(v, f)
-        oracle.set_options(False, float.fromhex("0x1.bb67b0p+0"))
+        oracle.set_options(True, float.fromhex("0x1.bb67b0p+0"))
         s1 = oracle.render_meshes([v], [f], az[None], el[None], di[None], 96, **kw)
     finally:
-        oracle.set_options(False, 0.0)
+        oracle.set_options()
     nrm_b = oracle.vertex_normals(v, f)
     assert np.array_equal(n3["pix_to_face"], base["pix_to_face"])
     assert 0 < np.abs(n3["images"] - base["images"]).max() < 1e-5
@@ -533,3 +533,33 @@ def test_soft_oracle_fragment_lists_are_sorted_and_fixed_lists_reproduce_the_ren
     assert (zb[..., 1:][both] >= zb[..., :-1][both]).all()                # ascending depth
     again = oracle.render_meshes_soft([v], [f], az[None], el[None], di[None], 40, blur, 6, dtype=np.float64, fixed_p2f=pf)
     assert np.abs(again["images"] - out["images"]).max() < 1e-12 and np.abs(again["dists"] - out["dists"]).max() < 1e-15
+
+
+def test_oracle_finite_differences_against_torch_autograd_c1(oracle):
+    """tests/golden/torch_restatement_grad.npz (make_torch_restatement_grad.py): BASELINE configs[0] differentiated by
+    torch.autograd through a second implementation made of torch ops, pixel -> face map held fixed (what PyTorch3D's hard
+    rasteriser does).  The oracle's fp64 central differences with ITS map held fixed — the yardstick of every gradient test
+    since round 1 — must agree with it: relative error <= 2e-3 of the largest derivative per parameter."""
+    fx = _fx("torch_restatement_grad.npz")
+    v, f = syn.synthetic_mesh("M", 0)
+    S = int(fx["c1_image_size"])
+    az, el, di = (fx["c1_" + k][None].astype(np.float32) for k in ("azim", "elev", "dist"))
+    kw = dict(obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
+    want = oracle.render_meshes([v], [f], az, el, di, S, **kw)
+    assert (want["pix_to_face"] != fx["c1_pix_to_face"].astype(np.int32)).sum() == 0   # same maps: same function
+    G = np.random.default_rng(int(fx["c1_g_seed"])).standard_normal((4, 3, S, S)).astype(np.float32)
+    v64 = v.astype(np.float64)
+    base = [x.astype(np.float64) for x in (az, el, di)]
+
+    def per_view_loss(a, e, d):
+        o = oracle.render_meshes([v64], [f], a, e, d, S, dtype=np.float64, fixed_p2f=want["pix_to_face"], **kw)
+        return (o["images"][0] * G).sum(axis=(1, 2, 3))
+    for k, (name, h) in enumerate((("azim", 1e-4), ("elev", 1e-4), ("dist", 1e-5))):
+        plus, minus = [x.copy() for x in base], [x.copy() for x in base]
+        plus[k] += h
+        minus[k] -= h
+        fd = (per_view_loss(*plus) - per_view_loss(*minus)) / (2 * h)
+        ref = fx["c1_grad_" + name].astype(np.float64)
+        rel = np.abs(fd - ref).max() / np.abs(ref).max()
+        print("%s: oracle FD vs torch autograd, max relative error %.2e (|grad| up to %.3g)" % (name, rel, np.abs(ref).max()))
+        assert rel <= 1e-4, (name, fd, ref)   # (observed: 6e-6 ... 1.5e-5)

@@ -22,19 +22,23 @@ def render(vl, fl, az, el, di, S):
 
 
 def report(name, vl, fl, az, el, di, S):
-    orc.set_options(False, 0.0)
+    orc.set_options()
     base = render(vl, fl, az, el, di, S)
     cov = base["pix_to_face"] >= 0
     print("%s: %d pixels, %d covered" % (name, cov.size, int(cov.sum())))
-    for label, opts in (("normals as three cross products", (True, 0.0)), ("s = K[0][0] of torch CPU (0x1.bb67b0p+0, +1 ulp)", (False, S_TORCH_CPU)),
-                        ("s = numpy tanf route (%s, -1 ulp)" % float(np.float32(S32)).hex(), (False, S32))):
+    for label, opts, fma in (("normals as ONE cross product per face", (False, 0.0), False),
+                             ("s = K[0][0] of torch CPU (0x1.bb67b0p+0, +1 ulp)", (True, S_TORCH_CPU), False),
+                             ("s = numpy tanf route (%s, -1 ulp)" % float(np.float32(S32)).hex(), (True, S32), False),
+                             ("edge_fma: face test contracted as nvcc would (switch #3)", (True, 0.0), True)):
         orc.set_options(*opts)
+        orc.set_edge_fma(fma)
         o = render(vl, fl, az, el, di, S)
+        orc.set_edge_fma(False)
         moved = o["pix_to_face"] != base["pix_to_face"]
         d = np.abs(o["images"] - base["images"]).max(2).reshape(moved.shape)
-        print("   %-52s pixel -> face changes at %4d pixels; max colour change %.2e overall, %.2e on unchanged pixels; pixels > 1e-4: %d" % (
+        print("   %-60s pixel -> face changes at %4d pixels; max colour change %.2e overall, %.2e on unchanged pixels; pixels > 1e-4: %d" % (
             label, int(moved.sum()), d.max(), d[~moved].max(), int((d > 1e-4).sum())))
-    orc.set_options(False, 0.0)
+    orc.set_options()
 
 
 v, f = syn.synthetic_mesh("M", 0)
