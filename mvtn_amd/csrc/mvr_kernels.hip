@@ -65,7 +65,7 @@ static_assert(MVR_RB == 256, "the rasterisers' LDS layouts and their host-side s
 #define MVR_RB_WAVES_PER_SIMD 4
 #endif
 #ifndef MVR_FAST_WAVES_PER_SIMD
-#define MVR_FAST_WAVES_PER_SIMD 4
+#define MVR_FAST_WAVES_PER_SIMD 4          // (5: 96 VGPRs and 32 256 B of LDS fit, measured 80.9 vs 77.4 us at C2: the 5th workgroup buys nothing, the spills cost)
 #endif
 #define MVR_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define MVR_NACC 18
