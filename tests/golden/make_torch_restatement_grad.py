@@ -38,8 +38,8 @@ KEPS = r1.KEPS
 
 
 def pix_centres(S):
-    idx = torch.arange(S, dtype=torch.float32)
-    c = -1.0 + (2.0 * idx + 1.0) / S
+    idx = torch.arange(S, dtype=torch.get_default_dtype())
+    c = (-1.0 + (2.0 * idx.float() + 1.0) / S).to(idx.dtype)   # the fp32 pixel centres, as the rasteriser sees them
     py = c.flip(0)[:, None].expand(S, S)
     px = c.flip(0)[None, :].expand(S, S)
     return px, py
@@ -77,7 +77,7 @@ def phong_diff(p2f, bary, verts, faces, normals, cam_center, light_dir, obj, bg)
     direction = F.normalize(light_dir[None, None, :].expand(S, S, 3), p=2, dim=-1, eps=1e-6)
     cos_angle = torch.sum(nrm * direction, dim=-1)
     diffuse = torch.tensor([0.3, 0.3, 0.3]) * F.relu(cos_angle)[..., None]
-    lit = (cos_angle > 0).to(torch.float32)
+    lit = (cos_angle > 0).to(cos_angle.dtype)
     view_direction = F.normalize(cam_center[None, None, :] - pixel_coords, p=2, dim=-1, eps=1e-6)
     reflect = -direction + 2 * (cos_angle[..., None] * nrm)
     alpha = F.relu(torch.sum(view_direction * reflect, dim=-1)) * lit
@@ -88,36 +88,49 @@ def phong_diff(p2f, bary, verts, faces, normals, cam_center, light_dir, obj, bg)
     return out.permute(2, 0, 1)
 
 
-def render_views_diff(verts, faces, az, el, di, S, relative_light, g_seed):
-    """One mesh, V views: images with the pixel -> face map fixed, loss = sum(G * images), gradients by autograd."""
-    V = len(az)
-    a, e, d = (torch.from_numpy(np.asarray(x, np.float32)).clone().requires_grad_(True) for x in (az, el, di))
+def _project(verts, faces, a, e, d, V):
     R, T = r1.look_at_view_transform(d, e, a)
     W2V = r1.world_to_view_matrix(R, T)
     K = r1.fov_projection_matrix(V)
     view = r1.transform_points(verts[None].expand(V, -1, -1), W2V)
     ndc_xy = r1.transform_points(view, K)
-    ndc = torch.cat([ndc_xy[..., :2], view[..., 2:3]], dim=-1)       # the rasteriser keeps the view depth
-    nrm = r1.verts_normals(verts, faces)
-    centers = torch.inverse(W2V)[:, 3, :3]
-    lights = r1.camera_position_from_spherical_angles(d, e, a) if relative_light else None
-    obj = bg = (0.99999, 0.99999, 0.99999)
-    G = torch.from_numpy(np.random.default_rng(g_seed).standard_normal((V, 3, S, S)).astype(np.float32))
-    loss = torch.zeros(())
-    p2f_all, img_all = [], []
-    for n in range(V):
-        with torch.no_grad():
-            p2f, _, _ = r1.rasterize(ndc[n].detach(), faces, S)
-        bary = bary_of_winners(ndc[n], faces, p2f)
-        light = lights[n] if relative_light else torch.tensor([0.0, 1.0, 0.0])
-        img = phong_diff(p2f, bary, verts, faces, nrm, centers[n], light, obj, bg)
-        loss = loss + (img * G[n]).sum()
-        p2f_all.append(p2f)
-        img_all.append(img.detach())
-        print("  view", n, "covered", float((p2f >= 0).float().mean()), flush=True)
-    loss.backward()
-    return (torch.stack(p2f_all).numpy().astype(np.int16), torch.stack(img_all).numpy(),
-            a.grad.numpy().copy(), e.grad.numpy().copy(), d.grad.numpy().copy())
+    return torch.cat([ndc_xy[..., :2], view[..., 2:3]], dim=-1), W2V      # the rasteriser keeps the view depth
+
+
+def render_views_diff(verts, faces, az, el, di, S, relative_light, g_seed):
+    """One mesh, V views.  Pass 1 (fp32, no grad): the pixel -> face maps of the fp32 forward.  Pass 2 (the same torch ops in
+    float64, maps held fixed): loss = sum(G * images), gradients by torch.autograd — in double so that the fixture is the
+    derivative of the restated function itself, not that plus the rounding noise of an fp32 backward (with the random G the
+    sums cancel heavily: an fp32 autograd pass differs from fp64 central differences by ~1e-3 of the largest derivative)."""
+    V = len(az)
+    with torch.no_grad():
+        ndc32, _ = _project(verts, faces, *(torch.from_numpy(np.asarray(x, np.float32)) for x in (az, el, di)), V)
+        p2f_all = [r1.rasterize(ndc32[n], faces, S)[0] for n in range(V)]
+    torch.set_default_dtype(torch.float64)
+    try:
+        vd = verts.double()
+        a, e, d = (torch.from_numpy(np.asarray(x, np.float32)).double().requires_grad_(True) for x in (az, el, di))
+        ndc, W2V = _project(vd, faces, a, e, d, V)
+        nrm = r1.verts_normals(vd, faces)
+        centers = torch.inverse(W2V)[:, 3, :3]
+        lights = r1.camera_position_from_spherical_angles(d, e, a) if relative_light else None
+        obj = bg = (float(np.float32(0.99999)),) * 3
+        G = torch.from_numpy(np.random.default_rng(g_seed).standard_normal((V, 3, S, S)).astype(np.float32)).double()
+        loss = torch.zeros(())
+        img_all = []
+        for n in range(V):
+            bary = bary_of_winners(ndc[n], faces, p2f_all[n])
+            light = lights[n] if relative_light else torch.tensor([0.0, 1.0, 0.0])
+            img = phong_diff(p2f_all[n], bary, vd, faces, nrm, centers[n], light, obj, bg)
+            loss = loss + (img * G[n]).sum()
+            img_all.append(img.detach())
+            print("  view", n, "covered", float((p2f_all[n] >= 0).double().mean()), flush=True)
+        loss.backward()
+        out = (torch.stack(p2f_all).numpy().astype(np.int16), torch.stack(img_all).numpy(),
+               a.grad.numpy().copy(), e.grad.numpy().copy(), d.grad.numpy().copy())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return out
 
 
 def c3_views(B, V, seed):
