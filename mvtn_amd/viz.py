@@ -53,23 +53,48 @@ def save_grid(image_batch, save_path, nrow=8):
     Image.fromarray(rgb.numpy()).save(save_path)
 
 
-def save_cameras(cameras, save_path, scale=0.22, dpi=200):
-    """util.py:604-664: wireframe of every camera in world space."""
-    import matplotlib
-    matplotlib.use("Agg")
-    import matplotlib.pyplot as plt
+def camera_wireframe(scale=0.3):
+    """util.py:585-601 get_camera_wireframe: the 11-point polyline of a camera's frustum in camera space (apex = point 5)."""
     a = 0.5 * torch.tensor([-2.0, 1.5, 4.0])
     b = 0.5 * torch.tensor([2.0, 1.5, 4.0])
     c = 0.5 * torch.tensor([-2.0, -1.5, 4.0])
     d = 0.5 * torch.tensor([2.0, -1.5, 4.0])
     C = torch.zeros(3)
-    wire = torch.stack([a, b, d, c, a, C, b, d, C, c, C]) * scale
-    world = cameras.get_world_to_view_transform().inverse().transform_points(wire.to(cameras.R.device)).cpu()
+    return torch.stack([a, b, d, c, a, C, b, d, C, c, C]) * scale
+
+
+def plot_cameras(ax, cameras, color="blue", scale=0.3):
+    """util.py:604-618: every camera's wireframe in world space on a 3-D axis; the plot's (x, y, z) are the world's
+    (x, z, y) — "the Z and Y axes are flipped intentionally here" — line width 0.3.  Returns the line handles."""
+    wire = camera_wireframe(scale).to(cameras.R.device)
+    world = cameras.get_world_to_view_transform().inverse().transform_points(wire).detach().cpu()
+    handles = []
+    for w in world:
+        x_, z_, y_ = w.numpy().T.astype(float)
+        (h,) = ax.plot(x_, y_, z_, color=color, linewidth=0.3)
+        handles.append(h)
+    return handles
+
+
+def cameras_figure(cameras, scale=0.22):
+    """The figure util.py:655-664 save_cameras draws: axis limits (-3, 3) x (-3, 3) x (-1.8, 1.8), the world origin as a red
+    marker, the cameras in blue.  Returns (figure, axis, line handles)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
     fig = plt.figure()
     ax = fig.add_subplot(projection="3d")
-    for w in world:
-        x, z, y = w.numpy().T  # the reference plots (x, z, y)
-        ax.plot(x, y, z, color="#FF7D1E", linewidth=0.6)
-    ax.set_xlabel("x"); ax.set_ylabel("z"); ax.set_zlabel("y")
+    ax.set_xlim(-3.0, 3.0)
+    ax.set_ylim(-3.0, 3.0)
+    ax.set_zlim(-1.8, 1.8)
+    ax.scatter(xs=[0], ys=[0], zs=[0], linewidth=3, c="r")
+    handles = plot_cameras(ax, cameras, color="blue", scale=scale)
+    return fig, ax, handles
+
+
+def save_cameras(cameras, save_path, scale=0.22, dpi=200):
+    """util.py:655-664."""
+    import matplotlib.pyplot as plt
+    fig, _, _ = cameras_figure(cameras, scale)
     fig.savefig(save_path, dpi=dpi)
     plt.close(fig)

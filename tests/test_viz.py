@@ -85,3 +85,43 @@ def test_save_grid_honours_the_extension(tmp_path):
     with open(path, "rb") as f:
         assert f.read(3) == b"\xff\xd8\xff"
     assert Image.open(path).size == (3 * 10 + 2, 12)
+
+
+def test_camera_plot_draws_every_camera_where_it_is():
+    """util.py:604-664 (missing 4: the plot was only checked by its file size).  The figure's line handles are read
+    back: one polyline per camera, 11 points each; its apex (point 5 of the wireframe, the camera-space origin) sits at the
+    camera centre -T R^T; the plot's (x, y, z) are the world's (x, z, y); the frustum's four corners keep their camera-space
+    distances from the apex (a rigid transform); limits, origin marker and colours are the reference's."""
+    pytest = __import__("pytest")
+    pytest.importorskip("matplotlib")
+    import matplotlib.pyplot as plt
+    import numpy as np
+    from mvtn_amd import functional as F  # noqa: F401  (import check only: the plot needs no GPU)
+    az, el, di = torch.tensor([0.0, 90.0, 200.0, -45.0]), torch.tensor([30.0, -20.0, 60.0, 0.0]), torch.tensor([2.2, 1.5, 3.0, 2.0])
+    # look-at in torch (SURVEY A.1): C = d (cos e sin a, sin e, cos e cos a); z = -C / |C|, x = up x z, y = z x x; R columns = axes
+    a, e = torch.deg2rad(az), torch.deg2rad(el)
+    C = torch.stack([di * torch.cos(e) * torch.sin(a), di * torch.sin(e), di * torch.cos(e) * torch.cos(a)], 1)
+    z = torch.nn.functional.normalize(-C, dim=1)
+    x = torch.nn.functional.normalize(torch.cross(torch.tensor([[0.0, 1.0, 0.0]]).expand_as(z), z, dim=1), dim=1)
+    y = torch.nn.functional.normalize(torch.cross(z, x, dim=1), dim=1)
+    R = torch.stack([x, y, z], dim=2)
+    T = -torch.bmm(R.transpose(1, 2), C[:, :, None])[:, :, 0]
+    fig, ax, handles = viz.cameras_figure(Cameras(R, T, "perspective"), scale=0.22)
+    try:
+        assert len(handles) == 4
+        wire = viz.camera_wireframe(0.22).numpy()
+        for n, h in enumerate(handles):
+            xs, ys, zs = (np.asarray(v, dtype=np.float64) for v in h.get_data_3d())
+            assert xs.shape == (11,)
+            world = np.stack([xs, zs, ys], 1)                      # plot (x, y, z) = world (x, z, y)
+            assert np.allclose(world[5], C[n].numpy(), atol=1e-5)   # the apex is the camera centre
+            assert np.allclose(world[8], world[5]) and np.allclose(world[10], world[5])
+            for k in (0, 1, 2, 3):                                 # the image-plane corners: rigid transform of the wireframe
+                assert abs(np.linalg.norm(world[k] - world[5]) - np.linalg.norm(wire[k])) < 1e-5
+            centre_of_plane = world[[0, 1, 2, 3]].mean(0)          # lies on the optical axis, towards the origin the cameras look at
+            assert np.linalg.norm(centre_of_plane) < np.linalg.norm(world[5])
+            assert h.get_color() == "blue" and abs(h.get_linewidth() - 0.3) < 1e-9
+        assert tuple(ax.get_xlim()) == (-3.0, 3.0) and tuple(ax.get_ylim()) == (-3.0, 3.0) and tuple(ax.get_zlim()) == (-1.8, 1.8)
+        assert len(ax.collections) == 1                            # the red origin marker
+    finally:
+        plt.close(fig)
