@@ -1049,6 +1049,234 @@ template <typename T> MVR_HD void soft_fragment_bwd(const PixelGradIn<T> &cam, T
   acc[15] += g_l.x; acc[16] += g_l.y; acc[17] += g_l.z;
 }
 
+// Backward of one soft fragment that lies on a PIECE of a face the z-clip plane cuts (round 4; rounds 2-3 differentiated the whole
+// face, which is the wrong function next to the clip line: the piece's edge there is a silhouette edge of its own, and it moves
+// with the camera).  The forward is PyTorch3D's: clip_faces() turns the face into one or two triangles whose new vertices lie on
+// the edges leaving the lone vertex p1, at the view-depth parameter w = (z1 - zc) / (z1 - z_other); the rasteriser runs on the
+// piece; its (clipped) barycentrics b_k are mapped back to the face's, B_j = sum_k b_k beta_kj, for the colour; depth and signed
+// distance are the piece's.  In VIEW space a new vertex is P1 + w (P_other - P1): everything below is the chain rule through
+// that — piece vertices Q_k (view space) -> NDC -> edge functions, perspective correction, clip -> b_k -> (B_j, z, dist), and
+// back: dL/dQ_k, then to the face's own vertices (directly, or through (1 - w, w) and dw/dz), then R, T.  `sub`: which piece
+// (clip_face's t0 / t1).  Same accumulators as soft_fragment_bwd.
+// (used by k_mesh_soft_backward_cut, a launch of its own: inlined into — or called from — k_mesh_soft_backward's pixel loop this
+// rare path made the register allocator spill in the common one: 0.93 -> 2.4-2.6 ms)
+template <typename T> MVR_HD void soft_fragment_bwd_piece(const PixelGradIn<T> &cam, T px, T py, bool clip_bary, int shade,
+                                                          const V3<T> &X0, const V3<T> &X1, const V3<T> &X2,
+                                                          const V3<T> &N0, const V3<T> &N1, const V3<T> &N2,
+                                                          const V3<T> &c0, const V3<T> &c1, const V3<T> &c2,
+                                                          const V3<T> &G, T gzbuf, T gdist, T zc, int sub, T acc[18]) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+  const V3<T> Pv0 = world_to_view(cam.R, cam.Tr, X0), Pv1 = world_to_view(cam.R, cam.Tr, X1), Pv2 = world_to_view(cam.R, cam.Tr, X2);
+  const bool h0 = Pv0.z < zc, h1 = Pv1.z < zc, h2 = Pv2.z < zc;
+  const int nb = (h0 ? 1 : 0) + (h1 ? 1 : 0) + (h2 ? 1 : 0);
+  if (nb == 0 || nb == 3) {   // (not cut in this view after all: the whole face)
+    soft_fragment_bwd<T>(cam, px, py, clip_bary, shade, X0, X1, X2, N0, N1, N2, c0, c1, c2, G, gzbuf, gdist, acc);
+    return;
+  }
+  auto pick = [](int i, const V3<T> &a, const V3<T> &b, const V3<T> &c) -> V3<T> { return i == 0 ? a : (i == 1 ? b : c); };
+  const bool alone = nb == 1;
+  const int i1 = (h2 == alone) ? 2 : ((h1 == alone) ? 1 : 0), i2 = i1 == 2 ? 0 : i1 + 1, i3 = i2 == 2 ? 0 : i2 + 1;
+  const V3<T> P1 = pick(i1, Pv0, Pv1, Pv2), P2 = pick(i2, Pv0, Pv1, Pv2), P3 = pick(i3, Pv0, Pv1, Pv2);
+  const T D2 = P1.z - P2.z, D3 = P1.z - P3.z;
+  const T w2 = (P1.z - zc) / D2, w3 = (P1.z - zc) / D3;
+  const V3<T> P4 = {P1.x + w2 * (P2.x - P1.x), P1.y + w2 * (P2.y - P1.y), P1.z + w2 * (P2.z - P1.z)};
+  const V3<T> P5 = {P1.x + w3 * (P3.x - P1.x), P1.y + w3 * (P3.y - P1.y), P1.z + w3 * (P3.z - P1.z)};
+  // piece vertices: kind 0 = p1, 1 = p2, 2 = p3, 3 = p4 (on p1 p2), 4 = p5 (on p1 p3)
+  int kd0, kd1, kd2;
+  if (nb == 1) { if (sub == 0) { kd0 = 3; kd1 = 1; kd2 = 4; } else { kd0 = 4; kd1 = 1; kd2 = 2; } }
+  else { kd0 = 0; kd1 = 3; kd2 = 4; }
+  auto vert_of = [&](int kd) -> V3<T> { return kd == 0 ? P1 : (kd == 1 ? P2 : (kd == 2 ? P3 : (kd == 3 ? P4 : P5))); };
+  const V3<T> Q0 = vert_of(kd0), Q1 = vert_of(kd1), Q2 = vert_of(kd2);
+  // beta_kj in the order (p1, p2, p3) of the face's vertices
+  auto beta_of = [&](int kd, T *bp1, T *bp2, T *bp3) {
+    *bp1 = kd == 0 ? (T)1 : (kd == 3 ? (T)1 - w2 : (kd == 4 ? (T)1 - w3 : (T)0));
+    *bp2 = kd == 1 ? (T)1 : (kd == 3 ? w2 : (T)0);
+    *bp3 = kd == 2 ? (T)1 : (kd == 4 ? w3 : (T)0);
+  };
+  T be0[3], be1[3], be2[3];
+  beta_of(kd0, &be0[0], &be0[1], &be0[2]); beta_of(kd1, &be1[0], &be1[1], &be1[2]); beta_of(kd2, &be2[0], &be2[1], &be2[2]);
+  // ---- forward on the piece ------------------------------------------------------------------------------------------
+  const T rz0 = trcp(Q0.z), rz1 = trcp(Q1.z), rz2 = trcp(Q2.z);
+  const T u0 = (cam.s * Q0.x) * rz0, v0 = (cam.s * Q0.y) * rz0, z0 = Q0.z;
+  const T u1 = (cam.s * Q1.x) * rz1, v1 = (cam.s * Q1.y) * rz1, z1 = Q1.z;
+  const T u2 = (cam.s * Q2.x) * rz2, v2 = (cam.s * Q2.y) * rz2, z2 = Q2.z;
+  const T area = edge_fn(u2, v2, u0, v0, u1, v1) + (T)kEps;
+  const T ra = trcp(area);
+  const T e0 = edge_fn(px, py, u1, v1, u2, v2), e1 = edge_fn(px, py, u2, v2, u0, v0), e2 = edge_fn(px, py, u0, v0, u1, v1);
+  const T a0 = e0 * ra, a1 = e1 * ra, a2 = e2 * ra;
+  T w0_ = a0, w1_ = a1, w2_ = a2, rden = (T)1;
+  bool den_clamped = false;
+  if (cam.persp) {
+    const T t0 = (a0 * z1) * z2, t1 = (z0 * a1) * z2, t2 = (z0 * z1) * a2;
+    const T sum = (t0 + t1) + t2;
+    rden = trcp(tmax(sum, (T)kEps));
+    den_clamped = !(sum > (T)kEps);
+    w0_ = t0 * rden; w1_ = t1 * rden; w2_ = t2 * rden;
+  }
+  const bool inside = w0_ > (T)0 && w1_ > (T)0 && w2_ > (T)0;
+  T x0 = w0_, x1 = w1_, x2 = w2_, rS = (T)1;
+  bool s_clamped = false;
+  if (clip_bary) {
+    x0 = tmax(tmin(w0_, (T)1), (T)0); x1 = tmax(tmin(w1_, (T)1), (T)0); x2 = tmax(tmin(w2_, (T)1), (T)0);
+    const T sm = (x0 + x1) + x2;
+    s_clamped = !(sm > (T)1e-5);
+    rS = trcp(tmax(sm, (T)1e-5));
+  }
+  const T b0 = x0 * rS, b1 = x1 * rS, b2 = x2 * rS;
+  // the face's barycentrics, in (p1, p2, p3) order, then in the face's own vertex order
+  const T Bp1 = (b0 * be0[0] + b1 * be1[0]) + b2 * be2[0], Bp2 = (b0 * be0[1] + b1 * be1[1]) + b2 * be2[1], Bp3 = (b0 * be0[2] + b1 * be1[2]) + b2 * be2[2];
+  auto unpick = [&](int j) -> T { return j == i1 ? Bp1 : (j == i2 ? Bp2 : Bp3); };
+  const T B0 = unpick(0), B1 = unpick(1), B2 = unpick(2);
+  // ---- colour backward: gradients of the FACE's barycentrics, of the camera centre and of the light (as soft_fragment_bwd) ----
+  T gB0, gB1, gB2;
+  V3<T> g_cc = {(T)0, (T)0, (T)0}, g_l = {(T)0, (T)0, (T)0};
+  if (shade == 0) {
+    const V3<T> p = {(B0 * X0.x + B1 * X1.x) + B2 * X2.x, (B0 * X0.y + B1 * X1.y) + B2 * X2.y, (B0 * X0.z + B1 * X1.z) + B2 * X2.z};
+    const V3<T> n = {(B0 * N0.x + B1 * N1.x) + B2 * N2.x, (B0 * N0.y + B1 * N1.y) + B2 * N2.y, (B0 * N0.z + B1 * N1.z) + B2 * N2.z};
+    const V3<T> tex = {(B0 * c0.x + B1 * c1.x) + B2 * c2.x, (B0 * c0.y + B1 * c1.y) + B2 * c2.y, (B0 * c0.z + B1 * c1.z) + B2 * c2.z};
+    T idn, idl, idv;
+    bool cn, cl, cv;
+    const V3<T> nh = normalize_rs(n, (T)kNormalizeEps, &idn, &cn);
+    V3<T> lh = cam.l;
+    idl = (T)1; cl = true;
+    if (!cam.l_is_unit) lh = normalize_rs(cam.l, (T)kNormalizeEps, &idl, &cl);
+    const T cosang = dot(nh, lh);
+    const bool lit = cosang > (T)0;
+    const V3<T> view = {cam.cc.x - p.x, cam.cc.y - p.y, cam.cc.z - p.z};
+    const V3<T> vh = normalize_rs(view, (T)kNormalizeEps, &idv, &cv);
+    const V3<T> refl = {-lh.x + (T)2 * (cosang * nh.x), -lh.y + (T)2 * (cosang * nh.y), -lh.z + (T)2 * (cosang * nh.z)};
+    const T dvr = dot(vh, refl);
+    const bool spec_on = lit && dvr > (T)0;
+    const T alpha = spec_on ? dvr : (T)0;
+    const T sc = cam.ph.ambient + cam.ph.diffuse * (lit ? cosang : (T)0);
+    const V3<T> g_tex = {G.x * sc, G.y * sc, G.z * sc};
+    const T g_sc = (G.x * tex.x + G.y * tex.y) + G.z * tex.z;
+    T g_cos = lit ? cam.ph.diffuse * g_sc : (T)0;
+    V3<T> g_nh = {(T)0, (T)0, (T)0}, g_lh = {(T)0, (T)0, (T)0}, g_p = {(T)0, (T)0, (T)0};
+    if (spec_on) {
+      const T g_spec = (G.x + G.y) + G.z;
+      const T dpow = cam.ph.shininess * pow_shininess(alpha, cam.ph.shininess - (T)1);
+      const T g_dvr = cam.ph.specular * dpow * g_spec;
+      const V3<T> g_vh = {g_dvr * refl.x, g_dvr * refl.y, g_dvr * refl.z};
+      const V3<T> g_r = {g_dvr * vh.x, g_dvr * vh.y, g_dvr * vh.z};
+      g_lh = {-g_r.x, -g_r.y, -g_r.z};
+      g_cos += (T)2 * dot(g_r, nh);
+      g_nh = {(T)2 * cosang * g_r.x, (T)2 * cosang * g_r.y, (T)2 * cosang * g_r.z};
+      const V3<T> g_view = normalize_rs_bwd(vh, idv, cv, g_vh);
+      g_cc = g_view;
+      g_p = {-g_view.x, -g_view.y, -g_view.z};
+    }
+    g_nh = {g_nh.x + g_cos * lh.x, g_nh.y + g_cos * lh.y, g_nh.z + g_cos * lh.z};
+    g_lh = {g_lh.x + g_cos * nh.x, g_lh.y + g_cos * nh.y, g_lh.z + g_cos * nh.z};
+    const V3<T> g_n = normalize_rs_bwd(nh, idn, cn, g_nh);
+    g_l = cam.l_is_unit ? g_lh : normalize_rs_bwd(lh, idl, cl, g_lh);
+    gB0 = (dot(g_p, X0) + dot(g_n, N0)) + dot(g_tex, c0);
+    gB1 = (dot(g_p, X1) + dot(g_n, N1)) + dot(g_tex, c1);
+    gB2 = (dot(g_p, X2) + dot(g_n, N2)) + dot(g_tex, c2);
+  } else {
+    gB0 = dot(G, c0); gB1 = dot(G, c1); gB2 = dot(G, c2);
+  }
+  // face barycentrics in (p1, p2, p3) order -> piece barycentrics and the map's own parameters
+  const T gBp1 = i1 == 0 ? gB0 : (i1 == 1 ? gB1 : gB2), gBp2 = i2 == 0 ? gB0 : (i2 == 1 ? gB1 : gB2), gBp3 = i3 == 0 ? gB0 : (i3 == 1 ? gB1 : gB2);
+  T gb0 = (gBp1 * be0[0] + gBp2 * be0[1]) + gBp3 * be0[2], gb1 = (gBp1 * be1[0] + gBp2 * be1[1]) + gBp3 * be1[2],
+    gb2 = (gBp1 * be2[0] + gBp2 * be2[1]) + gBp3 * be2[2];
+  // d B / d w2, d B / d w3: a new vertex's row of beta is (1 - w, w) on (p1, other)
+  auto gw_beta = [&](int kd, T bk, T *g2, T *g3) {
+    if (kd == 3) *g2 += bk * (gBp2 - gBp1);
+    if (kd == 4) *g3 += bk * (gBp3 - gBp1);
+  };
+  T gw2 = (T)0, gw3 = (T)0;
+  gw_beta(kd0, b0, &gw2, &gw3); gw_beta(kd1, b1, &gw2, &gw3); gw_beta(kd2, b2, &gw2, &gw3);
+  // depth: z = sum b_k z_k (the piece's)
+  gb0 += gzbuf * z0; gb1 += gzbuf * z1; gb2 += gzbuf * z2;
+  T gz0 = gzbuf * b0, gz1 = gzbuf * b1, gz2 = gzbuf * b2;
+  T gwb0 = gb0, gwb1 = gb1, gwb2 = gb2;
+  if (clip_bary) {
+    const T sdot = s_clamped ? (T)0 : (gb0 * b0 + gb1 * b1) + gb2 * b2;
+    const T gx0 = (gb0 - sdot) * rS, gx1 = (gb1 - sdot) * rS, gx2 = (gb2 - sdot) * rS;
+    gwb0 = (w0_ > (T)0 && w0_ < (T)1) ? gx0 : (T)0;
+    gwb1 = (w1_ > (T)0 && w1_ < (T)1) ? gx1 : (T)0;
+    gwb2 = (w2_ > (T)0 && w2_ < (T)1) ? gx2 : (T)0;
+  }
+  T ga0 = gwb0, ga1 = gwb1, ga2 = gwb2;
+  if (cam.persp) {
+    T gt0, gt1, gt2;
+    if (den_clamped) { gt0 = gwb0 * rden; gt1 = gwb1 * rden; gt2 = gwb2 * rden; }
+    else {
+      const T s_ = (gwb0 * w0_ + gwb1 * w1_) + gwb2 * w2_;
+      gt0 = (gwb0 - s_) * rden; gt1 = (gwb1 - s_) * rden; gt2 = (gwb2 - s_) * rden;
+    }
+    ga0 = gt0 * (z1 * z2); gz1 += gt0 * (a0 * z2); gz2 += gt0 * (a0 * z1);
+    ga1 = gt1 * (z0 * z2); gz0 += gt1 * (a1 * z2); gz2 += gt1 * (z0 * a1);
+    ga2 = gt2 * (z0 * z1); gz0 += gt2 * (z1 * a2); gz1 += gt2 * (z0 * a2);
+  }
+  const T ge0 = ga0 * ra, ge1 = ga1 * ra, ge2 = ga2 * ra;
+  const T g_area = -((ga0 * a0 + ga1 * a1) + ga2 * a2) * ra;
+  T gu0 = (T)0, gv0 = (T)0, gu1 = (T)0, gv1 = (T)0, gu2 = (T)0, gv2 = (T)0;
+  gu1 += ge0 * (py - v2); gv1 += ge0 * (u2 - px); gu2 += ge0 * (v1 - py); gv2 += ge0 * (px - u1);
+  gu2 += ge1 * (py - v0); gv2 += ge1 * (u0 - px); gu0 += ge1 * (v2 - py); gv0 += ge1 * (px - u2);
+  gu0 += ge2 * (py - v1); gv0 += ge2 * (u1 - px); gu1 += ge2 * (v0 - py); gv1 += ge2 * (px - u0);
+  gu2 += g_area * (v1 - v0); gv2 += g_area * (-(u1 - u0));
+  gu0 += g_area * (v2 - v1); gv0 += g_area * (u1 - u2);
+  gu1 += g_area * (v0 - v2); gv1 += g_area * (u2 - u0);
+  if (gdist != (T)0) {
+    int edge;
+    T t;
+    const V3<T> E0 = {u0, v0, z0}, E1 = {u1, v1, z1}, E2 = {u2, v2, z2};
+    (void)point_triangle_dist2(px, py, E0, E1, E2, &edge, &t);
+    const T ax = edge == 2 ? u1 : u0, ay = edge == 2 ? v1 : v0, bx = edge == 0 ? u1 : u2, by = edge == 0 ? v1 : v2;
+    T wa, wb, rx, ry;
+    if (t < (T)0) { wa = (T)0; wb = (T)1; rx = px - bx; ry = py - by; }
+    else { wa = (T)1 - t; wb = t; rx = px - (ax + t * (bx - ax)); ry = py - (ay + t * (by - ay)); }
+    const T sgn = inside ? (T)-1 : (T)1;
+    const T k = (T)-2 * sgn * gdist;
+    const T gax = k * wa * rx, gay = k * wa * ry, gbx = k * wb * rx, gby = k * wb * ry;
+    if (edge == 2) { gu1 += gax; gv1 += gay; } else { gu0 += gax; gv0 += gay; }
+    if (edge == 0) { gu1 += gbx; gv1 += gby; } else { gu2 += gbx; gv2 += gby; }
+  }
+  // projection backward: gradient w.r.t. the piece's VIEW-space vertices
+  auto proj_bwd_v = [&](T rz, T u, T v, T gu, T gv, T gz) -> V3<T> {
+    return {gu * cam.s * rz, gv * cam.s * rz, gz - (gu * u + gv * v) * rz};
+  };
+  const V3<T> gQ0 = proj_bwd_v(rz0, u0, v0, gu0, gv0, gz0), gQ1 = proj_bwd_v(rz1, u1, v1, gu1, gv1, gz1), gQ2 = proj_bwd_v(rz2, u2, v2, gu2, gv2, gz2);
+  // piece vertices -> (p1, p2, p3) of the face, and the two clip parameters
+  V3<T> gP1 = {(T)0, (T)0, (T)0}, gP2 = gP1, gP3 = gP1;
+  auto scatter = [&](int kd, const V3<T> &g) {
+    if (kd == 0) { gP1 = {gP1.x + g.x, gP1.y + g.y, gP1.z + g.z}; }
+    else if (kd == 1) { gP2 = {gP2.x + g.x, gP2.y + g.y, gP2.z + g.z}; }
+    else if (kd == 2) { gP3 = {gP3.x + g.x, gP3.y + g.y, gP3.z + g.z}; }
+    else if (kd == 3) {
+      gP1 = {gP1.x + ((T)1 - w2) * g.x, gP1.y + ((T)1 - w2) * g.y, gP1.z + ((T)1 - w2) * g.z};
+      gP2 = {gP2.x + w2 * g.x, gP2.y + w2 * g.y, gP2.z + w2 * g.z};
+      gw2 += (g.x * (P2.x - P1.x) + g.y * (P2.y - P1.y)) + g.z * (P2.z - P1.z);
+    } else {
+      gP1 = {gP1.x + ((T)1 - w3) * g.x, gP1.y + ((T)1 - w3) * g.y, gP1.z + ((T)1 - w3) * g.z};
+      gP3 = {gP3.x + w3 * g.x, gP3.y + w3 * g.y, gP3.z + w3 * g.z};
+      gw3 += (g.x * (P3.x - P1.x) + g.y * (P3.y - P1.y)) + g.z * (P3.z - P1.z);
+    }
+  };
+  scatter(kd0, gQ0); scatter(kd1, gQ1); scatter(kd2, gQ2);
+  // w = (z1 - zc) / (z1 - zo): dw/dz1 = (zc - zo) / (z1 - zo)^2, dw/dzo = (z1 - zc) / (z1 - zo)^2
+  {
+    const T r2 = (T)1 / (D2 * D2), r3 = (T)1 / (D3 * D3);
+    gP1.z += gw2 * (zc - P2.z) * r2 + gw3 * (zc - P3.z) * r3;
+    gP2.z += gw2 * (P1.z - zc) * r2;
+    gP3.z += gw3 * (P1.z - zc) * r3;
+  }
+  // (p1, p2, p3) -> the face's own vertices, then R, T through Xv = Xw R + T
+  auto to_acc = [&](const V3<T> &Xw, const V3<T> &g) {
+    acc[0] += Xw.x * g.x; acc[1] += Xw.x * g.y; acc[2] += Xw.x * g.z;
+    acc[3] += Xw.y * g.x; acc[4] += Xw.y * g.y; acc[5] += Xw.y * g.z;
+    acc[6] += Xw.z * g.x; acc[7] += Xw.z * g.y; acc[8] += Xw.z * g.z;
+    acc[9] += g.x; acc[10] += g.y; acc[11] += g.z;
+  };
+  to_acc(pick(i1, X0, X1, X2), gP1); to_acc(pick(i2, X0, X1, X2), gP2); to_acc(pick(i3, X0, X1, X2), gP3);
+  acc[12] += g_cc.x; acc[13] += g_cc.y; acc[14] += g_cc.z;
+  acc[15] += g_l.x; acc[16] += g_l.y; acc[17] += g_l.z;
+}
+
 // softmax_rgb_blend / sigmoid_alpha_blend constants (renderer/blending.py): znear 1, zfar 100, eps 1e-10
 MVR_HD float texp(float x) { return expf(x); }
 MVR_HD double texp(double x) { return exp(x); }

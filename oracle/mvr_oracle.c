@@ -38,6 +38,13 @@ void orc_set_options(int normals_three_cross, double fov_scale_override) {
   orc_fov_scale_override = fov_scale_override > 0.0 ? fov_scale_override : 0.0;
 }
 void orc_set_edge_fma(int on) { orc_edge_fma = on ? 1 : 0; }
+/* soft path, round 4: which PIECE of a cut face every fragment of the K-nearest lists lies on (clip_face's index; -1: the face
+ * is whole) — written by the next orc_render_meshes_soft_* call when `out` is set ((N,H,W,K) int32), and, with a fixed list,
+ * read from `fixed` so that the listed fragments are evaluated on the same pieces again (finite differences of the clipped
+ * rendering).  Both NULL (the default) = the behaviour of rounds 2-3: fixed lists evaluate whole faces. */
+static int32_t *orc_soft_piece_out = NULL;
+static const int32_t *orc_soft_fixed_piece = NULL;
+void orc_set_soft_pieces(int32_t *out, const int32_t *fixed) { orc_soft_piece_out = out; orc_soft_fixed_piece = fixed; }
 
 #define REAL float
 #define SUFFIX _f32

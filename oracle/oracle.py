@@ -171,7 +171,7 @@ def render_meshes_soft(verts_list, faces_list, azim, elev, dist, image_size, blu
                        sigma=1e-4, gamma=1e-4, clip_barycentric_coords=True, light_dir=((0.0, 1.0, 0.0),),
                        obj_color=(1.0, 1.0, 1.0), bg_color=(1.0, 1.0, 1.0), vert_colors=None, perspective_correct=True,
                        cull_backfaces=False, fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0,
-                       fixed_p2f=None, dtype=np.float32, R=None, T=None, z_clip=0.0):
+                       fixed_p2f=None, dtype=np.float32, R=None, T=None, z_clip=0.0, fixed_piece=None):
     """Soft rasterisation + SoftPhongShader ("soft_phong") / SoftSilhouetteShader ("soft_silhouette") — SURVEY 8 f4.
     Returns dict(images (B,V,4,H,W) RGBA, pix_to_face / zbuf / dists (N,H,W,K), bary (N,H,W,K,3), R, T)."""
     sfx, cty = _sfx(dtype)
@@ -192,6 +192,11 @@ def render_meshes_soft(verts_list, faces_list, azim, elev, dist, image_size, blu
     p2f = np.empty((N, H, W, K), np.int32)
     zbuf, dists, bary = np.empty((N, H, W, K), dtype), np.empty((N, H, W, K), dtype), np.empty((N, H, W, K, 3), dtype)
     fixed = None if fixed_p2f is None else np.ascontiguousarray(fixed_p2f, np.int32)
+    # pieces of cut faces (round 4): returned as "pix_to_piece" (-1: whole face); with fixed_p2f, `fixed_piece` (the array a
+    # free render returned) makes the listed fragments be evaluated on the same pieces — without it fixed lists evaluate WHOLE faces
+    piece_out = np.full((N, H, W, K), -1, np.int32)
+    fpiece = None if fixed_piece is None else np.ascontiguousarray(fixed_piece, np.int32)
+    lib().orc_set_soft_pieces(_ptr(piece_out), _ptr(fpiece))
     getattr(lib(), "orc_render_meshes_soft" + sfx)(
         ctypes.c_int(B), ctypes.c_int(V), ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(K),
         _ptr(verts), _ptr(faces), _ptr(vert_off), _ptr(face_off), _ptr(R), _ptr(T),
@@ -200,7 +205,8 @@ def render_meshes_soft(verts_list, faces_list, azim, elev, dist, image_size, blu
         cty(fov), cty(ambient), cty(diffuse), cty(specular), cty(shininess), cty(blur_radius), cty(sigma), cty(gamma),
         ctypes.c_int({"soft_phong": 0, "soft_silhouette": 1}[shader]), _ptr(fixed), cty(z_clip),
         _ptr(images), _ptr(p2f), _ptr(zbuf), _ptr(dists), _ptr(bary))
-    return dict(images=images, pix_to_face=p2f, zbuf=zbuf, dists=dists, bary=bary, R=R, T=T)
+    lib().orc_set_soft_pieces(None, None)
+    return dict(images=images, pix_to_face=p2f, pix_to_piece=piece_out, zbuf=zbuf, dists=dists, bary=bary, R=R, T=T)
 
 
 def render_points(points, azim, elev, dist, image_size, radius=0.006, obj_color=(1.0, 1.0, 1.0),
