@@ -300,6 +300,17 @@ def main():
     for _ in range(args.warmup):
         out = step()
     elapsed = timed(step, args.steps, barrier, dist_on, dev)
+    # the host's share of a step: Python + dispatch + launches of 10 steps at a time with an empty queue in front and a
+    # synchronize behind (inside the K-step region above the host runs into the queue's depth and waits for the GPU there)
+    host_s = 0.0
+    for _ in range(10):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            step()
+        host_s += time.perf_counter() - t0
+    torch.cuda.synchronize()
+    host_enqueue_ms = host_s / 100 * 1e3
     out = render()
     value = n_views_total * args.steps / elapsed
 
@@ -509,10 +520,13 @@ def main():
             "prewarm_steps": prewarm,   # untimed steps in front of the W warm-up steps (--prewarm): untimed in all = prewarm + W
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if fixed_total else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "host_enqueue_ms_per_step": host_enqueue_ms,   # Python + dispatch + kernel launches per step, measured with an empty queue (10 x 10 steps after the timed region)
             "config": {"workload": wl,
                        "objects_per_gpu": B, "views_per_object": V, "image_size": H, "rotation_check": args.rotation_check,
                        "inputs": "CPU meshes packed + copied every step" if args.host_meshes else "resident in HBM",
                        "issue": "eager: one MVRenderer.forward%s per step from Python" % (" + backward" if args.workload == "mesh_fwdbwd" else ""),
+                       "autograd_node": None if args.workload == "points_fwd" or soft else
+                                        ("C++ (torch.ops.mvr.render_mesh_views, csrc/mvr_torch_op.cpp)" if _lib.torch_op() is not None else "Python (functional._RenderMeshViews)"),
                        "untimed_steps_before_the_timed_region": prewarm + args.warmup,
                        "parallelism": ("objects sharded over %d GPU(s); " % world) +
                                       ("one RCCL all-gather of the rendered views per step" if gather_in_step else "no data-path collective")},

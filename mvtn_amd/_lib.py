@@ -162,6 +162,42 @@ def load():
     return lib
 
 
+_TORCH_OP = False   # False: not tried yet; None: unavailable (the Python autograd node of functional.py is used)
+
+
+def torch_op():
+    """`torch.ops.mvr` — the mesh step as ONE torch operator with a C++ autograd node (csrc/mvr_torch_op.cpp: host-side
+    plumbing over the same C ABI calls) — or None: MVR_TORCH_OP=0, or the extension is not there and cannot be built here
+    (no g++ / read-only tree).  Then the Python `torch.autograd.Function` of functional.py issues the same calls."""
+    global _TORCH_OP
+    if _TORCH_OP is not False:
+        return _TORCH_OP
+    _TORCH_OP = None
+    if os.environ.get("MVR_TORCH_OP", "1") == "0":
+        return None
+    import torch
+    try:
+        path = _build.build_torch_op()
+    except Exception as e:  # noqa: BLE001
+        if not os.path.exists(_build.TORCH_OP_PATH):
+            return None
+        import warnings
+        warnings.warn("mvtn_amd: %s could not be rebuilt (%s); the Python autograd node is used" % (_build.TORCH_OP_PATH, e), RuntimeWarning)
+        return None
+    lib = load()
+    try:
+        torch.ops.load_library(path)
+        addr = [ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in
+                ("mvr_render_mesh_views_forward", "mvr_render_mesh_views_backward", "mvr_render_meshes_backward", "mvr_look_at_backward",
+                 "mvr_camera_position_backward", "mvr_mesh_workspace_bytes", "mvr_last_error")]
+        torch.ops.mvr.init(addr)
+        _TORCH_OP = torch.ops.mvr
+    except Exception as e:  # noqa: BLE001
+        import warnings
+        warnings.warn("mvtn_amd: %s did not load (%s); the Python autograd node is used" % (path, e), RuntimeWarning)
+    return _TORCH_OP
+
+
 def check(rc, what=""):
     if rc != MVR_OK:
         msg = load().mvr_last_error()

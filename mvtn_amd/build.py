@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libmvr_hip.so")
 HOSTMATH_PATH = os.path.join(_HERE, "libmvr_hostmath.so")
+TORCH_OP_PATH = os.path.join(_HERE, "_mvr_torch_op.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                # coverage / depth arithmetic must be the exact IEEE sequence written in mvr_math.h
@@ -133,6 +134,58 @@ def build_hostmath(force=False):
     if r.returncode != 0:
         raise RuntimeError("g++ failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
     return HOSTMATH_PATH
+
+
+def _torch_op_sources():
+    return [os.path.join(CSRC, "mvr_torch_op.cpp"), os.path.join(os.path.dirname(_HERE), "include", "mvr.h")]
+
+
+def torch_op_hash():
+    """Content hash of the torch operator's sources + the torch build it is compiled against (its C++ ABI is torch's)."""
+    import torch
+    return _src_hash(_torch_op_sources(), ["torch-" + torch.__version__])
+
+
+def torch_op_is_current():
+    try:
+        with open(_hash_path(TORCH_OP_PATH)) as f:
+            return os.path.exists(TORCH_OP_PATH) and f.read().strip() == torch_op_hash()
+    except OSError:
+        return False
+
+
+def build_torch_op(force=False):
+    """g++ -> mvtn_amd/_mvr_torch_op.so: host-side plumbing (csrc/mvr_torch_op.cpp: the mesh step as one torch operator with a
+    C++ autograd node).  No kernels, no link against libmvr_hip.so (the entry points are handed over as addresses); links
+    against the torch of this interpreter.  Same lock / rename discipline as build_hip."""
+    if not force and torch_op_is_current():
+        return TORCH_OP_PATH
+    from torch.utils import cpp_extension as ce
+    import torch
+    with open(TORCH_OP_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and torch_op_is_current():
+                return TORCH_OP_PATH
+            tmp = "%s.tmp.%d" % (TORCH_OP_PATH, os.getpid())
+            cmd = (["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)] +
+                   ["-I" + d for d in ce.include_paths()] + [_torch_op_sources()[0], "-o", tmp] +
+                   ["-L" + d for d in ce.library_paths()] + ["-ltorch", "-ltorch_cpu", "-lc10"])
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError("g++ failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+                os.replace(tmp, TORCH_OP_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            htmp = "%s.tmp.%d" % (_hash_path(TORCH_OP_PATH), os.getpid())
+            with open(htmp, "w") as f:
+                f.write(torch_op_hash() + "\n")
+            os.replace(htmp, _hash_path(TORCH_OP_PATH))
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return TORCH_OP_PATH
 
 
 if __name__ == "__main__":

@@ -343,6 +343,20 @@ def render_mesh_views(packed: PackedMeshes, azim, elev, dist, light_dir, params,
     need_grad = torch.is_grad_enabled() and (azim.requires_grad or elev.requires_grad or dist.requires_grad)
     if azim.dim() != 1:   # (the renderer hands over flat views already: a second reshape is another tensor object each)
         azim, elev, dist = azim.reshape(-1), elev.reshape(-1), dist.reshape(-1)
+    op = _lib.torch_op()
+    if op is not None:
+        # the same two library calls from a C++ autograd node (csrc/mvr_torch_op.cpp): no Python in the backward, no ctypes
+        # marshalling, the buffers allocated natively — the host cost of a training step stays well below its GPU time
+        _require_cuda(azim, elev, dist, packed.verts)
+        pt = params.__dict__.get("_as_tensor")
+        if pt is None:   # zero-copy view of the ctypes struct (always current)
+            pt = params.__dict__["_as_tensor"] = torch.frombuffer(params, dtype=torch.uint8)
+        keep = getattr(params, "_keep", None)
+        seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        return tuple(op.render_mesh_views(_f32c(azim), _f32c(elev), _f32c(dist), None if light_dir is None else _f32c(light_dir), getattr(host_status, "tensor", host_status),
+                                          packed.verts, packed.faces, packed.vert_off, packed.face_off, packed.vert_colors,
+                                          packed.max_faces, packed.max_verts, pt, [t for t in keep if t is not None] if keep else [],
+                                          int(max_trials), seed - (1 << 64) if seed >= (1 << 63) else seed, _stream(), need_grad))
     return _RenderMeshViews.apply(azim, elev, dist, packed, params, light_dir, max_trials, seed, host_status, need_grad)
 
 

@@ -174,3 +174,56 @@ def test_soft_backward_on_cut_faces_against_finite_differences(shader, K, zc):
         worst = max(worst, rel)
         print("%s z_clip %.1f %s: relative error %.3g (|grad| up to %.3g)" % (shader, zc, name, rel, np.abs(ref).max()))
     assert worst < 1e-3, worst   # (observed: <= 3.3e-5 with and without cut faces)
+
+
+# ---- the C++ autograd node (csrc/mvr_torch_op.cpp) against the Python one (functional._RenderMeshViews) -------------------------
+# Both are plumbing over the same two C ABI calls; the operator exists for its host cost.  Same inputs ->
+# the same bytes out of both, for the images, the cameras, the status words and the three gradients, on every branch of the
+# backward: images only (the training step), images + cameras (the chained fall-back), cameras only, a window of draws.
+@pytest.mark.gpu
+@pytest.mark.parametrize("light", ["fixed", "relative"])
+@pytest.mark.parametrize("through", ["images", "images+cameras", "cameras", "window"])
+def test_torch_operator_matches_the_python_autograd_node(light, through):
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib
+    from mvtn_amd.regularize import draw_regularization
+    dev = _dev()
+    op = _lib.torch_op()
+    assert op is not None, "mvtn_amd/_mvr_torch_op.so is not loaded (MVR_TORCH_OP=0, or the build failed)"
+    B, V, S = 3, 6, 96
+    vl, fl = zip(*[syn.synthetic_mesh("S", i) for i in range(B)])
+    packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl]), dev)
+    az, el, di = syn.spherical_views(V)
+    rng = np.random.default_rng(5)
+    az, el, di = (np.tile(x, (B, 1)) + rng.uniform(-3, 3, (B, V)).astype(np.float32) * s for x, s in ((az, 1), (el, 1), (di, 0.02)))
+    up = torch.randn(B, V, 3, S, S, device=dev, generator=torch.Generator(dev).manual_seed(3))
+    draws = None
+    if through == "window":
+        torch.manual_seed(11)
+        draws = draw_regularization(B, V, S, dev, dropout_p=0.3, augment_training=True, crop_ratio=0.3)
+
+    def run(use_op):
+        saved = _lib._TORCH_OP
+        _lib._TORCH_OP = saved if use_op else None
+        try:
+            ta, te, td = (_t(x).to(dev).requires_grad_(True) for x in (az, el, di))
+            r = MVRenderer(V, S, pc_rendering=False, light_direction=light).eval()
+            img, cams = r(packed, None, ta, te, td, **({"window": draws} if draws is not None else {}))
+            loss = 0
+            if through != "cameras":
+                loss = loss + (img * up).sum()
+            if through in ("images+cameras", "cameras"):
+                loss = loss + (cams.R * 0.37).sum() + (cams.T * -1.3).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            return [x.detach().cpu().numpy() for x in (img, cams.R, cams.T, ta.grad, te.grad, td.grad)]
+        finally:
+            _lib._TORCH_OP = saved
+    a, b = run(True), run(False)
+    for name, x, y in zip(("images", "R", "T", "grad_azim", "grad_elev", "grad_dist"), a, b):
+        assert x.shape == y.shape and x.tobytes() == y.tobytes(), "%s differs between the C++ and the Python node" % name
+    assert np.abs(a[3]).max() > 0
+    # without autograd: the same frames, no saved state
+    with torch.no_grad():
+        r = MVRenderer(V, S, pc_rendering=False, light_direction=light).eval()
+        img, _ = r(packed, None, _t(az).to(dev), _t(el).to(dev), _t(di).to(dev), **({"window": draws} if draws is not None else {}))
+    assert img.cpu().numpy().tobytes() == a[0].tobytes()
