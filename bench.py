@@ -300,13 +300,15 @@ def main():
     for _ in range(args.warmup):
         out = step()
     elapsed = timed(step, args.steps, barrier, dist_on, dev)
-    # the host's share of a step: Python + dispatch + launches of 10 steps at a time with an empty queue in front and a
-    # synchronize behind (inside the K-step region above the host runs into the queue's depth and waits for the GPU there)
+    # the host's share of a step: Python + dispatch + launches of 25 steps at a time with an empty queue in front and a
+    # synchronize behind (inside the K-step region above the host runs into the queue's depth and waits for the GPU there);
+    # the first step of a group is left out (the first launch after a synchronize pays the runtime's clean-up, see above)
     host_s = 0.0
-    for _ in range(10):
+    for _ in range(4):
         torch.cuda.synchronize()
+        step()
         t0 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(25):
             step()
         host_s += time.perf_counter() - t0
     torch.cuda.synchronize()
@@ -520,7 +522,7 @@ def main():
             "prewarm_steps": prewarm,   # untimed steps in front of the W warm-up steps (--prewarm): untimed in all = prewarm + W
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if fixed_total else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "host_enqueue_ms_per_step": host_enqueue_ms,   # Python + dispatch + kernel launches per step, measured with an empty queue (10 x 10 steps after the timed region)
+            "host_enqueue_ms_per_step": host_enqueue_ms,   # Python + dispatch + kernel launches per step, measured with a short queue (4 x 25 steps after the timed region)
             "config": {"workload": wl,
                        "objects_per_gpu": B, "views_per_object": V, "image_size": H, "rotation_check": args.rotation_check,
                        "inputs": "CPU meshes packed + copied every step" if args.host_meshes else "resident in HBM",
