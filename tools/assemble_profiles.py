@@ -58,6 +58,11 @@ if glob.glob("%s/pmc_sq1_mesh_fwd/**/*counter_collection.csv" % src, recursive=T
     sq["k_mesh_raster_fast (training step)"] = sq["k_mesh_raster_fast"]
     sq["k_mesh_raster_fast"] = pmc("%s/pmc_sq1_mesh_fwd" % src, "k_mesh_raster_fast")
 sq["k_points_raster_shade"] = pmc("%s/pmc_sq1_points_fwd" % src, "k_points_raster_shade")
+if glob.glob("%s/pmc_sq1_soft_fwdbwd/**/*counter_collection.csv" % src, recursive=True):
+    for kern in ("k_mesh_soft_forward", "k_mesh_soft_backward("):
+        sq[kern.rstrip("(")] = pmc("%s/pmc_sq1_soft_fwdbwd" % src, kern)
+if os.path.exists("%s/bench_driver_like.json" % src):
+    shutil.copy("%s/bench_driver_like.json" % src, "%s/%s_bench_driver_like.json" % (dst, tag))
 sq["_note"] = ("rocprofv3 --pmc passes of tools/collect_profiles.sh (C3 step for the mesh kernels, C4 for the points kernel); SQ_*_CYCLES / "
                "SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles summed over waves, SQ_BUSY_CYCLES = 32 x kernel cycles")
 sq["_prepass_hbm_bytes_per_launch"] = int((2 * fe + wr) * 1024)

@@ -21,6 +21,9 @@ timeout 200 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_C
 # (the forward rasteriser of the INFERENCE step: in the training step above it also writes the pixel lists)
 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_sq1_mesh_fwd -- python3 bench.py --workload mesh_fwd --steps 3 --warmup 2 --no-cpu-baseline --no-pipelined > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_sq1_points_fwd -- python3 bench.py --workload points_fwd --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d $out/pmc_sq1_soft_fwdbwd -- python3 bench.py --workload soft_fwdbwd --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+# what the driver runs at the end of the round (its flags; N = 1)
+timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_like.json 2> $out/bench_driver_like.err
 find $out -name "*kernel_trace.csv" -delete
 find $out -name "*agent_info.csv" -delete
 du -sh $out

@@ -1,7 +1,7 @@
 # developer scratch: dynamic VALU instruction count per phase of k_mesh_raster_fast via ablation builds
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for v in full "-DMVR_ABL_FAST_NO_ITEMS" "-DMVR_ABL_FAST_NO_ITEMS -DMVR_ABL_FAST_NO_RESOLVE" "-DMVR_ABL_NO_SHADE"; do
+for v in full "-DMVR_ABL_FAST_NO_ITEMS" "-DMVR_ABL_FAST_NO_ITEMS -DMVR_ABL_FAST_NO_RESOLVE" "-DMVR_ABL_FAST_RETURN_AT=2" "-DMVR_ABL_FAST_RETURN_AT=1" "-DMVR_ABL_FAST_RETURN_AT=0" "-DMVR_ABL_NO_SHADE"; do
   d=""; [ "$v" != full ] && d="$v"
   python3 mvtn_amd/build.py /tmp/libabl.so $d > /dev/null
   export MVR_LIB=/tmp/libabl.so
