@@ -441,3 +441,24 @@ def test_stale_library_is_refused_unless_opted_in(monkeypatch):
     with pytest.raises(ImportError, match="ABI version"):
         _lib.load()
     monkeypatch.setattr(_lib, "_LIB", real)
+
+
+def test_torch_operator_library_loads_and_refuses_cpu_tensors():
+    """mvtn_amd/_mvr_torch_op.so (csrc/mvr_torch_op.cpp: the mesh step as one torch operator with a C++ autograd node) builds,
+    registers `mvr::render_mesh_views` and receives the C ABI entry points; like every product path it has no CPU fallback:
+    host tensors are refused with a message, not rendered."""
+    import torch
+    from mvtn_amd import _lib, functional as F
+    op = _lib.torch_op()
+    assert op is not None, "the torch operator library did not build / load"
+    assert "render_mesh_views" in str(torch.ops.mvr.render_mesh_views)
+    p = F.mesh_params(2, 32, 1, (1.0, 1.0, 1.0), (1.0, 1.0, 1.0))
+    pt = torch.frombuffer(p, dtype=torch.uint8)
+    z = torch.zeros(2)
+    verts, faces = torch.zeros(3, 3), torch.zeros(1, 3, dtype=torch.int32)
+    off = torch.tensor([0, 3], dtype=torch.int32)
+    foff = torch.tensor([0, 1], dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="on the GPU"):
+        op.render_mesh_views(z, z, z, None, None, verts, faces, off, foff, None, 1, 3, pt, [], -1, 0, 0, False)
+    with pytest.raises(RuntimeError, match="mvr_mesh_params has"):
+        op.render_mesh_views(z, z, z, None, None, verts, faces, off, foff, None, 1, 3, pt[:-4].clone(), [], -1, 0, 0, False)
