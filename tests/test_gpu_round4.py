@@ -187,8 +187,10 @@ def test_torch_operator_matches_the_python_autograd_node(light, through):
     from mvtn_amd import MVRenderer, Meshes, PackedMeshes, _lib
     from mvtn_amd.regularize import draw_regularization
     dev = _dev()
+    if os.environ.get("MVR_TORCH_OP", "1") == "0":
+        pytest.skip("MVR_TORCH_OP=0: the C++ node is switched off for this run")
     op = _lib.torch_op()
-    assert op is not None, "mvtn_amd/_mvr_torch_op.so is not loaded (MVR_TORCH_OP=0, or the build failed)"
+    assert op is not None, "mvtn_amd/_mvr_torch_op.so is not loaded (the build failed)"
     B, V, S = 3, 6, 96
     vl, fl = zip(*[syn.synthetic_mesh("S", i) for i in range(B)])
     packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl]), dev)

@@ -449,6 +449,8 @@ def test_torch_operator_library_loads_and_refuses_cpu_tensors():
     host tensors are refused with a message, not rendered."""
     import torch
     from mvtn_amd import _lib, functional as F
+    if os.environ.get("MVR_TORCH_OP", "1") == "0":
+        pytest.skip("MVR_TORCH_OP=0: the C++ node is switched off for this run")
     op = _lib.torch_op()
     assert op is not None, "the torch operator library did not build / load"
     assert "render_mesh_views" in str(torch.ops.mvr.render_mesh_views)
