@@ -138,9 +138,9 @@ typedef struct mvr_points_params {
 } mvr_points_params;
 
 /* ABI generation of this header: bumped whenever a struct layout or an entry point's contract changes (101: fov_scale in
- * mvr_mesh_params, flag 64, 8-entry arrays of mvr_profile_end).  mvr_version() returns the value the library was built with;
+ * mvr_mesh_params, flag 64, 8-entry arrays of mvr_profile_end; 102: mvr_mesh_fast_stats).  mvr_version() returns the value the library was built with;
  * a loader must refuse a library whose value differs (mvtn_amd/_lib.py does). */
-#define MVR_ABI_VERSION 101
+#define MVR_ABI_VERSION 102
 int mvr_version(void);
 const char *mvr_last_error(void);
 /* Hash of the sources (and compiler flags) this library was built from, as mvtn_amd/build.py computes it: lets a loader
@@ -263,6 +263,12 @@ int mvr_mesh_clip_straddlers(const mvr_mesh_batch *meshes, const mvr_mesh_params
  * after a forward that ran the fast rasteriser (perspective-correct, no MVR_RASTER_EXACT_ONLY).  count: 1 device int. */
 int mvr_mesh_redo_count(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const void *workspace, size_t workspace_bytes,
                         int32_t *count, mvr_stream_t stream);
+
+/* More of the same, counts: 4 device ints: [0] the redo count above; [1] pixels whose depth order the fast rasteriser could not
+ * prove and settled with the reference's exact test inside its own workgroup (per strip capped at 255); [2] strip-list entries
+ * (a face is listed once per strip it reaches) wider than 16 pixels, rasterised by a whole wave; [3] strip-list entries in all. */
+int mvr_mesh_fast_stats(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const void *workspace, size_t workspace_bytes,
+                        int32_t *counts, mvr_stream_t stream);
 
 /* World-space area-weighted vertex normals (Meshes.verts_normals_packed, used by
  * HardPhongShader at :102).  normals: (total_verts, 3).  Uses `workspace` as scratch. */

@@ -10,7 +10,7 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 _vp = ctypes.c_void_p
 
 MVR_OK = 0
-MVR_ABI_VERSION = 101   # == MVR_ABI_VERSION of include/mvr.h == mvr_version() of the library
+MVR_ABI_VERSION = 102   # == MVR_ABI_VERSION of include/mvr.h == mvr_version() of the library
 MVR_CULL_BACKFACES = 1
 MVR_PERSPECTIVE_CORRECT = 2
 MVR_WORKSPACE_FROM_FORWARD = 4
@@ -91,6 +91,7 @@ PROTOTYPES = {
     "mvr_render_meshes_soft_backward": (ctypes.c_int, [_MB, _MP, ctypes.POINTER(SoftParams)] + [_vp] * 9 + [ctypes.c_size_t, _vp]),
     "mvr_mesh_clip_straddlers": (ctypes.c_int, [_MB, _MP, _vp, ctypes.c_size_t, _vp, _vp]),
     "mvr_mesh_redo_count": (ctypes.c_int, [_MB, _MP, _vp, ctypes.c_size_t, _vp, _vp]),
+    "mvr_mesh_fast_stats": (ctypes.c_int, [_MB, _MP, _vp, ctypes.c_size_t, _vp, _vp]),
     "mvr_vertex_normals": (ctypes.c_int, [_MB, _vp, _vp, ctypes.c_size_t, _vp]),
     "mvr_render_meshes_forward": (ctypes.c_int, [_MB, _MP, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "mvr_render_meshes_backward": (ctypes.c_int, [_MB, _MP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
@@ -179,10 +180,9 @@ def torch_op():
     try:
         path = _build.build_torch_op()
     except Exception as e:  # noqa: BLE001
-        if not os.path.exists(_build.TORCH_OP_PATH):
-            return None
         import warnings
-        warnings.warn("mvtn_amd: %s could not be rebuilt (%s); the Python autograd node is used" % (_build.TORCH_OP_PATH, e), RuntimeWarning)
+        warnings.warn("mvtn_amd: %s could not be %s (%s); the slower Python autograd node is used (MVR_TORCH_OP=0 silences this)" % (
+            _build.TORCH_OP_PATH, "rebuilt" if os.path.exists(_build.TORCH_OP_PATH) else "built", e), RuntimeWarning)
         return None
     lib = load()
     try:

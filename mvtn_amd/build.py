@@ -143,7 +143,10 @@ def _torch_op_sources():
 def torch_op_hash():
     """Content hash of the torch operator's sources + the torch build it is compiled against (its C++ ABI is torch's)."""
     import torch
-    return _src_hash(_torch_op_sources(), ["torch-" + torch.__version__])
+    # (the version string alone does not pin the C++ ABI: a rebuild of the same version with another libstdc++ ABI or from
+    # another commit would otherwise reuse a stale operator)
+    return _src_hash(_torch_op_sources(), ["torch-" + torch.__version__, "cxx11abi-%s" % int(bool(torch._C._GLIBCXX_USE_CXX11_ABI)),
+                                           "git-%s" % getattr(torch.version, "git_version", ""), "hip-%s" % getattr(torch.version, "hip", "")])
 
 
 def torch_op_is_current():

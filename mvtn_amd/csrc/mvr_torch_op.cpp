@@ -125,6 +125,10 @@ struct RenderMeshViews : public torch::autograd::Function<RenderMeshViews> {
 
   static variable_list backward(AutogradContext *ctx, variable_list grads_out) {
     const auto saved = ctx->get_saved_variables();
+    // forward() saves only when the caller asked for the gradient of azim / elev / dist (need_grad).  A node also exists when some
+    // OTHER tensor argument requires grad (light, verts, vert_colors, keep): none of those is differentiated here.
+    TORCH_CHECK(saved.size() == 14, "mvr::render_mesh_views: backward reached a node whose forward ran with need_grad = false — only azim, "
+                "elev and dist are differentiable (a light / vertex / colour tensor that requires grad gets no gradient from this operator)");
     const Tensor &azim = saved[0], &elev = saved[1], &dist = saved[2], &aux = saved[3], &R = saved[4], &T = saved[5], &light = saved[6], &p2f = saved[7], &ws = saved[8];
     const mvr_mesh_batch mb = mesh_batch(saved[9], saved[10], saved[11], saved[12], saved[13], ctx->saved_data["max_faces"].toInt(), ctx->saved_data["max_verts"].toInt());
     mvr_mesh_params p;

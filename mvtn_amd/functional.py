@@ -348,9 +348,10 @@ def render_mesh_views(packed: PackedMeshes, azim, elev, dist, light_dir, params,
         # the same two library calls from a C++ autograd node (csrc/mvr_torch_op.cpp): no Python in the backward, no ctypes
         # marshalling, the buffers allocated natively — the host cost of a training step stays well below its GPU time
         _require_cuda(azim, elev, dist, packed.verts)
-        pt = params.__dict__.get("_as_tensor")
-        if pt is None:   # zero-copy view of the ctypes struct (always current)
-            pt = params.__dict__["_as_tensor"] = torch.frombuffer(params, dtype=torch.uint8)
+        # zero-copy view of the ctypes struct, made per call (1.3 us).  NOT cached on `params`: the tensor's storage holds a
+        # reference to `params` inside C++, so params -> tensor -> params would be a cycle the garbage collector cannot see,
+        # and every `with_window` copy (one per training step, with four device tensors in `_keep`) would live forever
+        pt = torch.frombuffer(params, dtype=torch.uint8)
         keep = getattr(params, "_keep", None)
         seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         return tuple(op.render_mesh_views(_f32c(azim), _f32c(elev), _f32c(dist), None if light_dir is None else _f32c(light_dir), getattr(host_status, "tensor", host_status),

@@ -79,18 +79,15 @@ def load_mesh(path):
 
 
 def rotation_matrix(axis, theta, in_degrees=True):
-    """util.py:491-506 (Euler-Rodrigues): rotation about `axis` by `theta`."""
+    """The matrix util.py:491-506 returns — the rotation by `theta` about `axis`, counterclockwise when the axis points at the
+    viewer — written from Rodrigues' formula R = cos(theta) I + sin(theta) [k]x + (1 - cos(theta)) k k^T with k the unit axis
+    (the reference expands the same rotation from Euler parameters: equal to ~1e-16, tests/golden/rotation_matrix.json)."""
     if in_degrees:
         theta = math.radians(theta)
-    axis = np.asarray(axis, np.float64)
-    axis = axis / math.sqrt(np.dot(axis, axis))
-    a = math.cos(theta / 2.0)
-    b, c, d = -axis * math.sin(theta / 2.0)
-    aa, bb, cc, dd = a * a, b * b, c * c, d * d
-    bc, ad, ac, ab, bd, cd = b * c, a * d, a * c, a * b, b * d, c * d
-    return np.array([[aa + bb - cc - dd, 2 * (bc + ad), 2 * (bd - ac)],
-                     [2 * (bc - ad), aa + cc - bb - dd, 2 * (cd + ab)],
-                     [2 * (bd + ac), 2 * (cd - ab), aa + dd - bb - cc]])
+    k = np.asarray(axis, np.float64)
+    k = k / np.linalg.norm(k)
+    cross = np.array([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
+    return math.cos(theta) * np.eye(3) + math.sin(theta) * cross + (1.0 - math.cos(theta)) * np.outer(k, k)
 
 
 def torch_center_and_normalize(points, p="inf"):

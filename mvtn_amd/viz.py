@@ -54,13 +54,15 @@ def save_grid(image_batch, save_path, nrow=8):
 
 
 def camera_wireframe(scale=0.3):
-    """util.py:585-601 get_camera_wireframe: the 11-point polyline of a camera's frustum in camera space (apex = point 5)."""
+    """util.py:588-601 get_camera_wireframe: the 12-point polyline of a camera symbol in camera space — the frustum (apex =
+    point 5) and, last, the segment from the apex along the viewing direction to (0, 0, 3)."""
     a = 0.5 * torch.tensor([-2.0, 1.5, 4.0])
     b = 0.5 * torch.tensor([2.0, 1.5, 4.0])
     c = 0.5 * torch.tensor([-2.0, -1.5, 4.0])
     d = 0.5 * torch.tensor([2.0, -1.5, 4.0])
     C = torch.zeros(3)
-    return torch.stack([a, b, d, c, a, C, b, d, C, c, C]) * scale
+    ahead = torch.tensor([0.0, 0.0, 3.0])
+    return torch.stack([a, b, d, c, a, C, b, d, C, c, C, ahead]) * scale
 
 
 def plot_cameras(ax, cameras, color="blue", scale=0.3):

@@ -97,6 +97,32 @@ def test_synthetic_meshes():
     assert np.array_equal(v2, syn.synthetic_mesh("M", 0)[0]) and not np.array_equal(v2, v3)
 
 
+def test_cad_mesh_is_what_its_docstring_says():
+    """synthetic.cad_mesh (bench.py --geometry cad): the reference's geometry class — big flat triangles beside slivers, coincident
+    reversed duplicates (on shared and on duplicated vertices), exactly n_faces faces, normalised like custom_dataset.py:120-121."""
+    for seed in range(3):
+        v, f = syn.cad_mesh(seed)
+        assert f.shape == (5120, 3) and f.dtype == np.int64 and v.dtype == np.float32 and f.min() >= 0 and f.max() < len(v)
+        assert abs(np.linalg.norm(v, axis=1).max() - 1) < 1e-6 and np.abs(v.mean(0)).max() < 1e-5
+        a, b, c = (v[f[:, k]].astype(np.float64) for k in range(3))
+        area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+        assert area.max() > 100 * np.median(area)                       # two-triangle sides next to tessellated patches
+        edges = np.stack([np.linalg.norm(a - b, axis=1), np.linalg.norm(b - c, axis=1), np.linalg.norm(c - a, axis=1)], 1)
+        assert (edges.max(1) / np.maximum(edges.min(1), 1e-12) > 8).mean() > 0.15   # slivers
+        # coincident pairs: the same three POSITIONS with opposite winding, by index and by duplicated vertices
+        key = [tuple(sorted(map(tuple, tri))) for tri in v[f].tolist()]
+        from collections import Counter
+        n_dup = sum(1 for k, n in Counter(key).items() if n > 1)
+        assert 0.05 * len(f) < n_dup < 0.45 * len(f)
+        shared = sum(1 for k, n in Counter(tuple(sorted(t)) for t in f.tolist()).items() if n > 1)
+        assert 0 < shared < n_dup
+        assert np.array_equal(v, syn.cad_mesh(seed)[0])
+    assert syn.cad_mesh(0, n_faces=1280)[1].shape == (1280, 3)
+    assert syn.ragged_tiers(16).count("S") == 4 and syn.ragged_tiers(16).count("M") == 8 and syn.ragged_tiers(16).count("L") == 4
+    assert [len(syn.geometry_mesh("ragged", "M", i)[1]) for i in range(4)] == [1280, 5120, 20480, 5120]
+    assert len(syn.geometry_mesh("cad", "L", 1)[1]) == 20480 and len(syn.geometry_mesh("ico", "S", 1)[1]) == 1280
+
+
 def test_c_abi_library_exports_every_declared_symbol():
     """libmvr_hip.so loads without a GPU and exports exactly what include/mvr.h declares."""
     from mvtn_amd import _lib
@@ -107,7 +133,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libmvr_hip.so does not export %s" % name
     assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
-    assert lib.mvr_version() == _lib.MVR_ABI_VERSION == 101
+    assert lib.mvr_version() == _lib.MVR_ABI_VERSION == 102
     # struct layouts agree with the header (sizes computed by hand from include/mvr.h)
     assert ctypes.sizeof(_lib.MeshBatch) == 6 * 4 + 5 * 8
     assert ctypes.sizeof(_lib.MeshParams) == 6 * 4 + 5 * 4 + 6 * 4 + 4 + 6 * 4 + 4 * 8 + 8

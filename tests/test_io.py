@@ -70,6 +70,18 @@ def test_rotation_and_normalisation_match_the_reference_formulas():
     assert torch.allclose(mio.torch_center_and_normalize(pts, p="no"), pts - pts.mean(0))
 
 
+def test_rotation_matrix_against_the_reference_generated_golden():
+    """tests/golden/rotation_matrix.json: util.rotation_matrix of the reference itself (make_rotation_golden.py) on 25 axes /
+    angles; the Rodrigues form here equals it to rounding."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rotation_matrix.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 25
+    for c in cases:
+        assert np.abs(mio.rotation_matrix(c["axis"], c["theta_deg"]) - np.asarray(c["R"])).max() < 1e-15
+
+
 def test_mesh_from_file_yields_what_the_renderer_takes(tmp_path):
     p = tmp_path / "cube.off"
     p.write_text(CUBE_OFF)

@@ -89,7 +89,7 @@ def test_save_grid_honours_the_extension(tmp_path):
 
 def test_camera_plot_draws_every_camera_where_it_is():
     """util.py:604-664 (missing 4: the plot was only checked by its file size).  The figure's line handles are read
-    back: one polyline per camera, 11 points each; its apex (point 5 of the wireframe, the camera-space origin) sits at the
+    back: one polyline per camera, 12 points each (util.py:588-601: the last one, (0, 0, 3) scale, ends the segment along the viewing direction); its apex (point 5 of the wireframe, the camera-space origin) sits at the
     camera centre -T R^T; the plot's (x, y, z) are the world's (x, z, y); the frustum's four corners keep their camera-space
     distances from the apex (a rigid transform); limits, origin marker and colours are the reference's."""
     pytest = __import__("pytest")
@@ -112,7 +112,7 @@ def test_camera_plot_draws_every_camera_where_it_is():
         wire = viz.camera_wireframe(0.22).numpy()
         for n, h in enumerate(handles):
             xs, ys, zs = (np.asarray(v, dtype=np.float64) for v in h.get_data_3d())
-            assert xs.shape == (11,)
+            assert xs.shape == (12,)
             world = np.stack([xs, zs, ys], 1)                      # plot (x, y, z) = world (x, z, y)
             assert np.allclose(world[5], C[n].numpy(), atol=1e-5)   # the apex is the camera centre
             assert np.allclose(world[8], world[5]) and np.allclose(world[10], world[5])
@@ -120,6 +120,9 @@ def test_camera_plot_draws_every_camera_where_it_is():
                 assert abs(np.linalg.norm(world[k] - world[5]) - np.linalg.norm(wire[k])) < 1e-5
             centre_of_plane = world[[0, 1, 2, 3]].mean(0)          # lies on the optical axis, towards the origin the cameras look at
             assert np.linalg.norm(centre_of_plane) < np.linalg.norm(world[5])
+            # the twelfth point: 3 * scale along the viewing direction (+z of the camera, towards the origin it looks at)
+            ahead = world[11] - world[5]
+            assert abs(np.linalg.norm(ahead) - 3 * 0.22) < 1e-5 and np.allclose(ahead / np.linalg.norm(ahead), -C[n].numpy() / np.linalg.norm(C[n].numpy()), atol=1e-5)
             assert h.get_color() == "blue" and abs(h.get_linewidth() - 0.3) < 1e-9
         assert tuple(ax.get_xlim()) == (-3.0, 3.0) and tuple(ax.get_ylim()) == (-3.0, 3.0) and tuple(ax.get_zlim()) == (-1.8, 1.8)
         assert len(ax.collections) == 1                            # the red origin marker
