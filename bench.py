@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--views", type=int, default=0)
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--tier", default="M")
+    ap.add_argument("--geometry", default="ico", choices=["ico", "cad", "ragged"],
+                    help="mesh workloads: what the B objects are.  ico (default, the headline of every round): lumpy icospheres of --tier; "
+                         "cad: synthetic.cad_mesh of the tier's face count — boxes / plates as two big triangles per side, cylinder slivers, "
+                         "tessellated patches, ~30 %% of the parts doubled with reversed winding (coincident shells), parts inside parts: "
+                         "the geometry class of the reference's ModelNet40; ragged: icospheres of tiers S, M, L, M, S, ... (1 : 2 : 1)")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--rotation-check", default="device", choices=["device", "sync", "off"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,14 +104,14 @@ def cpu_baseline(args, V):
         dt = time.perf_counter() - t0
         sample = "%d views of cloud seed 0 (2048 pts, %d^2), literal pixel-major loop of RasterizePointsNaiveCpu" % (nviews, args.image_size)
     else:
-        v, f = syn.synthetic_mesh(args.tier, 0)
+        v, f = syn.geometry_mesh(args.geometry, args.tier, 1 if args.geometry == "ragged" else 0)   # (ragged: its first tier-M object)
         az, el, di = syn.spherical_views(V)
         az, el, di = az[None, :nviews], el[None, :nviews], di[None, :nviews]
         t0 = time.perf_counter()
         orc.render_meshes([v], [f], az, el, di, args.image_size, mode=0, return_fragments=False)
         dt = time.perf_counter() - t0
-        sample = "%d views of mesh seed 0 (tier %s, %d^2), literal pixel-major loop of RasterizeMeshesNaiveCpu + Phong (forward only)" % (
-            nviews, args.tier, args.image_size)
+        sample = "%d views of mesh seed 0 (%s, tier %s, %d^2), literal pixel-major loop of RasterizeMeshesNaiveCpu + Phong (forward only)" % (
+            nviews, args.geometry, args.tier, args.image_size)
     base = {"value": nviews / dt, "unit": "views/s", "cores": 1, "kind": "port", "sample": sample,
             "host_cores_available": os.cpu_count()}
     # the same loop with OpenMP over image rows on every host core; 4x the sample
@@ -122,8 +127,11 @@ def cpu_baseline(args, V):
                 orc.render_meshes([v], [f], az, el, di, args.image_size, mode=0, return_fragments=False)
         dt_all = time.perf_counter() - t0
         orc.set_threads(1)
-        base["all_cores"] = {"value": reps * nviews / dt_all, "unit": "views/s", "cores": ncores,
-                             "note": "same loop, OpenMP over image rows; not what upstream does (its CPU rasteriser is single-threaded)"}
+        # NOT an "all cores" baseline: the loop is parallel over the 224 image rows of ONE view only (no parallelism over views,
+        # a serial set-up per view), so it stops scaling at a few dozen threads; kept as what it is, under a name that says so
+        base["openmp_over_rows"] = {"value": reps * nviews / dt_all, "unit": "views/s", "threads": ncores,
+                                    "note": "the same loop with OpenMP over the image rows of one view at a time (SURVEY 8d ii); upstream's CPU "
+                                            "rasteriser is single-threaded — `value` above is the baseline"}
     return base
 
 
@@ -238,7 +246,7 @@ def main():
     else:
         vl, fl = [], []
         for i in range(B):
-            v, f = syn.synthetic_mesh(args.tier, seed0 + i)
+            v, f = syn.geometry_mesh(args.geometry, args.tier, seed0 + i)
             vl.append(torch.from_numpy(v))
             fl.append(torch.from_numpy(f))
             nv_list.append(len(v))
@@ -333,7 +341,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC passes of the same command, committed under profiles/ (FETCH_SIZE / WRITE_SIZE
     # cannot be read inside this process); `from_profiles` names the file so that a stale number is visible as such
     traffic, traffic_src = None, None
-    for tpath in ([] if (c5 or soft) else sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % args.workload)))[-1:]):
+    for tpath in ([] if (c5 or soft or args.geometry != "ico") else sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_traffic_%s.json" % args.workload)))[-1:]):
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             traffic_src = os.path.relpath(tpath, ROOT)
@@ -357,7 +365,7 @@ def main():
         import glob
         sqp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.json")))[-1]
         k = json.load(open(sqp)).get(kname)
-        if k and k.get("SQ_INSTS_VALU") and kern_ms > 0 and args.workload != "points_fwd" and not c5 and not soft:
+        if k and k.get("SQ_INSTS_VALU") and kern_ms > 0 and args.workload != "points_fwd" and not c5 and not soft and args.geometry == "ico":
             floor_ms = k["SQ_INSTS_VALU"] * 2.0 / 1024.0 / 2.07e9 * 1e3
             roofline["valu"] = {"wave_instructions": k["SQ_INSTS_VALU"], "cycles_per_instruction_floor": 2.0, "issue_floor_ms": floor_ms, "frac": floor_ms / kern_ms,
                                 "from_profiles": os.path.relpath(sqp, ROOT)}
@@ -479,6 +487,33 @@ def main():
             gather["views_per_s_with_overlapped_exchange"] = n_views_total * reps / to
             gather["exchange_pieces"] = chunks
 
+    # ---- what the fast rasteriser met on this geometry (mesh workloads, hard shader): one extra forward through the same library
+    # call with its diagnostics read back (mvr_mesh_fast_stats) + the pre-pass kernel's duration (profile kind 5)
+    fast_stats = None
+    if args.workload.startswith("mesh") and not soft and rank == 0 and not args.host_meshes:
+        from mvtn_amd import functional as F
+        with torch.no_grad():
+            Rm, Tm = F.look_at_view_transform(dist_t.detach().reshape(-1), elev.detach().reshape(-1), azim.detach().reshape(-1))
+            sp = F.mesh_params(V, H, 1, (0.99999,) * 3, (0.99999,) * 3, strip_rows=args.strip_rows)
+            _, _, st4 = F.render_meshes_fragments(packed, Rm, Tm, torch.tensor([[0.0, 1.0, 0.0]], device=dev), sp, return_stats=True)
+        st4 = [int(x) for x in st4.cpu()]
+        TH = args.strip_rows or 8
+        n_strips_all = B * V * ((H + TH - 1) // TH)
+        fast_stats = {"strips": n_strips_all, "strips_redone_by_exact_body": st4[0], "redo_fraction": st4[0] / n_strips_all,
+                      "ambiguous_pixels_settled_in_kernel": st4[1], "strip_list_entries": st4[3], "entries_on_wave_per_face_path": st4[2],
+                      "wide_share": (st4[2] / st4[3]) if st4[3] else None,
+                      "prepass_kernel_ms": None}
+        os.environ["MVR_PROF_MASK"] = "0x20"   # the pre-pass alone, in a pass of its own
+        lib.mvr_profile_begin()
+        for _ in range(min(args.steps, 200)):
+            render()
+        ms5, cnt5 = (ctypes.c_double * 8)(), (ctypes.c_int32 * 8)()
+        lib.mvr_profile_end(ms5, cnt5)
+        del os.environ["MVR_PROF_MASK"]
+        torch.cuda.synchronize()
+        if cnt5[5]:
+            fast_stats["prepass_kernel_ms"] = ms5[5] / cnt5[5]
+
     cpu = None
     parity = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -499,8 +534,13 @@ def main():
             vln = [vl[i].numpy() for i in range(nb)]
             fln = [fl[i].numpy() for i in range(nb)]
             ld = orc.camera_position(a_, e_, d_) if args.workload == "mesh_fwdbwd" else ((0.0, 1.0, 0.0),)
+            # cad: the oracle's switch #4 — vertex-normal sums accumulated order-independently, as the library does.  Coincident
+            # reversed shells on shared vertices have normals that cancel; a float sum there is noise of its summation order
+            # (oracle/mvr_oracle_impl.inc orc_vertex_normals; tests/test_gpu_round5.py shows that only those pixels differ)
+            orc.set_normals_exact_sum(args.geometry == "cad")
             want = orc.render_meshes(vln, fln, a_, e_, d_, H, light_dir=ld, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3,
                                      return_fragments=False)
+            orc.set_normals_exact_sum(False)
             parity = float(np.abs(img - want["images"]).max())
 
     if rank == 0:
@@ -512,8 +552,9 @@ def main():
         elif soft:
             wl = "C3 shape through SoftPhongShader: B=%d tier-%s meshes x %d jittered views, %dx%d, faces_per_pixel 4, sigma 1e-4, fwd+bwd" % (B, args.tier, V, H, W)
         else:
-            wl = {"mesh_fwd": "C2: B=%d tier-%s meshes x %d spherical views, %dx%d, mesh render fwd" % (B, args.tier, V, H, W),
-                  "mesh_fwdbwd": "C3: B=%d tier-%s meshes x %d jittered views, %dx%d, fwd+bwd (grad wrt azim/elev/dist, relative light)" % (B, args.tier, V, H, W),
+            geo = {"ico": "tier-%s" % args.tier, "cad": "CAD-like (cad_mesh, %d faces)" % nf_list[0], "ragged": "ragged tier-S/M/L/M"}[args.geometry]
+            wl = {"mesh_fwd": "C2: B=%d %s meshes x %d spherical views, %dx%d, mesh render fwd" % (B, geo, V, H, W),
+                  "mesh_fwdbwd": "C3: B=%d %s meshes x %d jittered views, %dx%d, fwd+bwd (grad wrt azim/elev/dist, relative light)" % (B, geo, V, H, W),
                   "points_fwd": "C4: B=%d clouds x 2048 pts x %d views, %dx%d, point render fwd" % (B, V, H, W)}[args.workload]
         line = {
             "metric": "rendered views/sec (224x224 point clouds, 20 views/obj)" if args.workload == "points_fwd" else
@@ -533,6 +574,8 @@ def main():
                        "parallelism": ("objects sharded over %d GPU(s); " % world) +
                                       ("one RCCL all-gather of the rendered views per step" if gather_in_step else "no data-path collective")},
             "roofline": roofline,
+            "geometry": args.geometry if args.workload.startswith("mesh") else None,
+            "fast_raster_stats": fast_stats,
             "cpu_baseline": cpu,
             "max_pixel_err_vs_oracle": parity,
         }

@@ -151,7 +151,8 @@ const char *mvr_source_hash(void);
  * HIP events recorded on the stream it is launched on.  mvr_profile_end synchronises on those events and
  * returns, per kind {0: mesh raster+shade forward, 1: points raster+shade forward, 2: mesh backward, 3: soft mesh
  * forward, 4: soft mesh backward, 5: mesh pre-pass, 6-7: unused}, the summed kernel time in ms and the number of launches
- * (both host arrays of length 8). */
+ * (both host arrays of length 8).  The environment variable MVR_PROF_MASK (read by mvr_profile_begin; bit k = kind k) selects
+ * the kinds; default 0xDF: all but the pre-pass, whose events would sit between the launches the mesh forward's timing brackets. */
 /* Self-test of the rasteriser's correctly rounded reciprocal (hardware v_rcp_f32 + two Newton steps) against the
  * IEEE division 1.0f / d for every float whose bit pattern lies in [lo_bits, hi_bits]; *n_bad (device) receives the
  * number of mismatches, *first_bad (device) one offending bit pattern.  Used by the GPU parity tests only. */

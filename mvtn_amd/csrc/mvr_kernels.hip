@@ -98,11 +98,12 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 #include <utility>
 enum { PROF_MESH_FWD = 0, PROF_POINTS_FWD = 1, PROF_MESH_BWD = 2, PROF_SOFT_FWD = 3, PROF_SOFT_BWD = 4, PROF_MESH_PREPASS = 5, PROF_KINDS = 8 };   // (6, 7: unused)
 static bool g_prof_on = false;
+static unsigned g_prof_mask = 0xDFu;   // kinds bracketed while profiling; the pre-pass (5) only when MVR_PROF_MASK asks: two event pairs back to back would sit in the gap the other kinds' timings see
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[PROF_KINDS];
 
 struct ProfScope {
   hipStream_t st; int kind; hipEvent_t stop; bool on;
-  ProfScope(int kind_, hipStream_t st_) : st(st_), kind(kind_), stop(nullptr), on(g_prof_on) {
+  ProfScope(int kind_, hipStream_t st_) : st(st_), kind(kind_), stop(nullptr), on(g_prof_on && ((g_prof_mask >> kind_) & 1u)) {
     if (!on) return;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }

@@ -361,10 +361,12 @@ def render_mesh_views(packed: PackedMeshes, azim, elev, dist, light_dir, params,
     return _RenderMeshViews.apply(azim, elev, dist, packed, params, light_dir, max_trials, seed, host_status, need_grad)
 
 
-def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params, return_redo=False, return_straddlers=False):
+def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params, return_redo=False, return_straddlers=False, return_stats=False):
     """(images, pix_to_face (N,H,W) int32 LOCAL face index / -1) without autograd — for parity tests.
     `return_redo`: also the number of (view, strip) tiles the fast rasteriser left to the exact kernel (a device int);
-    `return_straddlers`: also the number of faces that straddled the z-clip plane (and were cut there)."""
+    `return_straddlers`: also the number of faces that straddled the z-clip plane (and were cut there);
+    `return_stats`: also mvr_mesh_fast_stats' four device ints (strips redone, ambiguous pixels, strip-list entries rasterised
+    by a whole wave, strip-list entries in all)."""
     lib = _lib.load()
     R, T, light = _f32c(R), _f32c(T), _f32c(light_dir)
     _require_cuda(R, T, light, packed.verts)
@@ -384,6 +386,10 @@ def render_meshes_fragments(packed: PackedMeshes, R, T, light_dir, params, retur
     if return_straddlers:
         cnt = torch.zeros(1, dtype=torch.int32, device=R.device)
         _lib.check(lib.mvr_mesh_clip_straddlers(mb, params, ws.data_ptr(), ws_bytes, cnt.data_ptr(), _stream()), "mvr_mesh_clip_straddlers")
+        extra += (cnt,)
+    if return_stats:
+        cnt = torch.zeros(4, dtype=torch.int32, device=R.device)
+        _lib.check(lib.mvr_mesh_fast_stats(mb, params, ws.data_ptr(), ws_bytes, cnt.data_ptr(), _stream()), "mvr_mesh_fast_stats")
         extra += (cnt,)
     return (images, p2f) + extra
 

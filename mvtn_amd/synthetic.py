@@ -208,7 +208,8 @@ def geometry_mesh(geometry, tier, seed):
     """One object of bench.py's --geometry: "ico" (synthetic_mesh of `tier`), "cad" (cad_mesh with the tier's face count),
     "ragged" (synthetic_mesh, the tier following ragged_tiers)."""
     if geometry == "cad":
-        return cad_mesh(seed, n_faces=20 * 4 ** _TIER_LEVEL[tier])
+        import os   # (developer knob for tools/: the share of doubled parts, to separate the cost of coincident shells from the rest)
+        return cad_mesh(seed, n_faces=20 * 4 ** _TIER_LEVEL[tier], double_sided=float(os.environ.get("MVR_CAD_DOUBLE_SIDED", "0.3")))
     if geometry == "ragged":
         return synthetic_mesh(ragged_tiers(seed + 1)[seed], seed)
     return synthetic_mesh(tier, seed)

@@ -38,6 +38,10 @@ void orc_set_options(int normals_three_cross, double fov_scale_override) {
   orc_fov_scale_override = fov_scale_override > 0.0 ? fov_scale_override : 0.0;
 }
 void orc_set_edge_fma(int on) { orc_edge_fma = on ? 1 : 0; }
+/*   normals_exact_sum (round 5): 0 (default) = the vertex-normal sums as an index_add in face order; 1 = order-independent
+ *       64-bit fixed-point sums (see orc_vertex_normals).  Differs visibly only at vertices whose face normals cancel. */
+static int orc_normals_exact_sum = 0;
+void orc_set_normals_exact_sum(int on) { orc_normals_exact_sum = on ? 1 : 0; }
 /* soft path, round 4: which PIECE of a cut face every fragment of the K-nearest lists lies on (clip_face's index; -1: the face
  * is whole) — written by the next orc_render_meshes_soft_* call when `out` is set ((N,H,W,K) int32), and, with a fixed list,
  * read from `fixed` so that the listed fragments are evaluated on the same pieces again (finite differences of the clipped

@@ -58,6 +58,27 @@ def set_edge_fma(on=False):
     lib().orc_set_edge_fma(ctypes.c_int(int(bool(on))))
 
 
+def set_normals_exact_sum(on=False):
+    """Switch #4 (round 5): the vertex-normal sums accumulated order-independently in 64-bit fixed point (what libmvr_hip.so
+    does) instead of as a float index_add in face order (default; PyTorch3D on the GPU: float atomics in arrival order).  The
+    forms differ visibly only at vertices whose face normals CANCEL (coincident reversed shells on shared vertices), where the
+    float sums are rounding noise (orc_vertex_normals in mvr_oracle_impl.inc).  Process-wide."""
+    lib().orc_set_normals_exact_sum(ctypes.c_int(int(bool(on))))
+
+
+def cancelled_normal_vertices(verts, faces, rel=1e-4):
+    """Boolean (Vn,) mask of the vertices whose area-weighted face normals cancel: |sum_f n_f| < rel * sum_f |n_f| (float64)."""
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    n = np.cross(c - b, a - b)
+    acc, mag = np.zeros_like(v), np.zeros(len(v))
+    for k in range(3):
+        np.add.at(acc, f[:, k], n)
+        np.add.at(mag, f[:, k], np.linalg.norm(n, axis=1))
+    return np.linalg.norm(acc, axis=1) < rel * np.maximum(mag, 1e-300)
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 

@@ -1371,7 +1371,11 @@ def test_fast_rasteriser_equals_exact_kernel(name, specs, V, size, dist, jitter)
     if "soup" not in str(specs) and dist >= 1.6:   # (nearer than 1.5 the clip plane z = 0.5 cuts faces: those views take the exact path)
         assert out["fast"][2] <= n_strips // 100, "ordinary meshes should almost never need the exact path"
     if "soup" in str(specs):
-        assert out["fast"][2] > 0, "coincident double-sided faces must be undecidable for the fast path"
+        # coincident double-sided faces: undecidable for the affine depth keys.  Rounds 2-4 handed such strips to the exact kernel's
+        # body; round 5 settles the recorded (pixel, face) candidates inside the fast kernel (mvr_mesh_fast_stats counts them)
+        _, _, st = F.render_meshes_fragments(packed, R, T, light, F.mesh_params(V, size, 1, obj, bg), return_stats=True)
+        st = [int(x) for x in st.cpu()]
+        assert st[1] > 0 and st[0] == out["fast"][2], st
 
 
 def test_full_size_c2_all_meshes_against_the_oracle(oracle):

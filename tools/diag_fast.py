@@ -16,7 +16,8 @@ B, V, H = 16, 12, 224
 TIER = os.environ.get("MVR_TIER", "M")     # MVR_TIER=L: the C5 shard (8 tier-L meshes x 20 views)
 if TIER == "L":
     B, V = 8, 20
-vl, fl = zip(*[syn.synthetic_mesh(TIER, i) for i in range(B)])
+GEO = os.environ.get("MVR_GEOMETRY", "ico")   # ico / cad / ragged (bench.py --geometry)
+vl, fl = zip(*[syn.geometry_mesh(GEO, TIER, i) for i in range(B)])
 packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl]), dev)
 az, el, di = syn.spherical_views(V)
 ta, te, td = (torch.from_numpy(np.tile(x, (B, 1))).to(dev) for x in (az, el, di))
@@ -34,9 +35,11 @@ d = d[d[:, 5] > 0]
 tot = d[:, 5] - d[:, 0]
 print("workgroups with work: %d   cycles/workgroup mean %.0f max %.0f; listed faces mean %.0f; ambiguous pixels total %d" % (
     len(d), tot.mean(), tot.max(), d[:, 6].mean(), d[:, 7].sum()))
+print("cycles/workgroup percentiles 50 / 90 / 99 / max: %.0f / %.0f / %.0f / %.0f; sum of workgroup cycles %.3g (a CU holds 4: / 1024 / 2.1e9 = %.1f us if perfectly packed)" % (
+    np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), tot.sum(), tot.sum() / 1024 / 2.1e9 * 1e6))
 two = d[:, 2] > 0
-names = ["init (tables, key clear, first entries)", "raster (all segments, wave 0)", "wait for the other waves", "ambiguous pixels", "resolve + shade"]
-spans = [d[:, 1] - d[:, 0], d[:, 3] - d[:, 1], d[:, 4] - d[:, 3], 0 * tot, d[:, 5] - d[:, 4]]
+names = ["init (tables, key clear, first entries)", "raster (all segments, wave 0)", "wait for the other waves", "exact settle of the candidates + resolve + shade"]
+spans = [d[:, 1] - d[:, 0], d[:, 3] - d[:, 1], d[:, 4] - d[:, 3], d[:, 5] - d[:, 4]]
 for nme, sp in zip(names, spans):
     print("  %-42s %5.1f %%   mean %7.0f cycles" % (nme, 100 * sp.sum() / tot.sum(), sp.mean()))
 print("  two-segment workgroups: %.1f %%; their near segment (wave 0): mean %.0f cycles of raster %.0f" % (
@@ -46,7 +49,7 @@ for lo, hi in [(1, 65), (65, 129), (129, 257), (257, 385), (385, 513), (513, 100
     m = (nl >= lo) & (nl < hi)
     if m.any():
         print("    faces [%4d,%5d): %5.1f %% of wgs  total %7.0f  init %6.0f  raster %7.0f  wait %6.0f  resolve %7.0f" % (
-            lo, hi, 100 * m.mean(), tot[m].mean(), spans[0][m].mean(), spans[1][m].mean(), spans[2][m].mean(), spans[4][m].mean()))
+            lo, hi, 100 * m.mean(), tot[m].mean(), spans[0][m].mean(), spans[1][m].mean(), spans[2][m].mean(), spans[3][m].mean()))
 
 rs = buf.cpu().numpy().reshape(-1, 8)[(1 << 19) // 8:(1 << 19) // 8 + nblocks].astype(np.float64)
 rs = rs[rs[:, 5] > 0]
