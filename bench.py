@@ -73,6 +73,10 @@ def parse():
     ap.add_argument("--host-meshes", action="store_true", help="hand CPU meshes to every step (the reference's interface): packing + H2D inside the timed region; documentation only, never the headline")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (self-test of the N>1 code path)")
     ap.add_argument("--cpu-views", type=int, default=16, help="views in the cpu_baseline sample (~0.7 s each for meshes)")
+    ap.add_argument("--ref-n1", action="store_true",
+                    help="N > 1, workload c5: rank 0 also renders the WHOLE workload (all 64 objects) alone, after the timed regions, and "
+                         "the line carries `scaling_vs_one_gpu` — speed-up and efficiency of the N-GPU run against that one-GPU reference, "
+                         "render only and with the all-gather — so that one multi-GPU run yields the whole scaling statement")
     return ap.parse_args()
 
 
@@ -514,6 +518,39 @@ def main():
         if cnt5[5]:
             fast_stats["prepass_kernel_ms"] = ms5[5] / cnt5[5]
 
+    # ---- --ref-n1: the one-GPU reference of the strong-scaling statement, measured in THIS run by rank 0 (the other ranks wait)
+    scaling_ref = None
+    if args.ref_n1 and dist_on and fixed_total:
+        if rank == 0:
+            vla, fla = [], []
+            for i in range(64):
+                v, f = syn.geometry_mesh(args.geometry, args.tier, i)
+                vla.append(torch.from_numpy(v)); fla.append(torch.from_numpy(f))
+            packed_all = PackedMeshes.from_meshes(Meshes(vla, fla), dev)
+            az_a, el_a, di_a = (torch.from_numpy(np.tile(x, (64, 1))).to(dev) for x in (az, el, di))
+
+            def render_all():
+                with torch.no_grad():
+                    return renderer(packed_all, None, az_a, el_a, di_a)[0]
+            for _ in range(20):
+                render_all()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps1 = max(20, min(200, args.steps))
+            for _ in range(reps1):
+                render_all()
+            torch.cuda.synchronize()
+            t1 = (time.perf_counter() - t0) / reps1
+            v1 = 64 * V / t1
+            r_only = beside.get("render_only", {}).get("views_per_s", value)
+            scaling_ref = {"one_gpu_views_per_s": v1, "one_gpu_ms_per_step": t1 * 1e3, "n_gpus": world,
+                           "speedup_render_only": r_only / v1, "efficiency_render_only": r_only / v1 / world,
+                           "speedup_with_allgather": (value / v1) if gather_in_step else None,
+                           "efficiency_with_allgather": (value / v1 / world) if gather_in_step else None,
+                           "note": "strong scaling of the fixed 64-object workload: the same run's N-GPU rates over rank 0 rendering all 64 objects alone"}
+            del packed_all
+        dist.barrier()
+
     cpu = None
     parity = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -552,7 +589,7 @@ def main():
         elif soft:
             wl = "C3 shape through SoftPhongShader: B=%d tier-%s meshes x %d jittered views, %dx%d, faces_per_pixel 4, sigma 1e-4, fwd+bwd" % (B, args.tier, V, H, W)
         else:
-            geo = {"ico": "tier-%s" % args.tier, "cad": "CAD-like (cad_mesh, %d faces)" % nf_list[0], "ragged": "ragged tier-S/M/L/M"}[args.geometry]
+            geo = {"ico": "tier-%s" % args.tier, "cad": "CAD-like (cad_mesh, %d faces)" % (nf_list[0] if nf_list else 0), "ragged": "ragged tier-S/M/L/M"}[args.geometry]
             wl = {"mesh_fwd": "C2: B=%d %s meshes x %d spherical views, %dx%d, mesh render fwd" % (B, geo, V, H, W),
                   "mesh_fwdbwd": "C3: B=%d %s meshes x %d jittered views, %dx%d, fwd+bwd (grad wrt azim/elev/dist, relative light)" % (B, geo, V, H, W),
                   "points_fwd": "C4: B=%d clouds x 2048 pts x %d views, %dx%d, point render fwd" % (B, V, H, W)}[args.workload]
@@ -580,6 +617,8 @@ def main():
             "max_pixel_err_vs_oracle": parity,
         }
         line.update(beside)
+        if scaling_ref:
+            line["scaling_vs_one_gpu"] = scaling_ref
         if gather:
             line["allgather"] = gather
         if dist_on:

@@ -114,6 +114,17 @@ struct ProfScope {
   ~ProfScope() { if (on) (void)hipEventRecord(stop, st); }
 };
 
+// Scheduling hints — wave priorities (s_setprio) in the mesh rasterisers, the start stagger (s_sleep) of the point rasteriser's first
+// resident batch: timing only, never results.  -DMVR_NO_TUNING compiles them out; tests/test_gpu_round5.py builds that variant and
+// checks that mesh and point renders at 128 / 224 / 448 pixels are bit-identical with and without them.
+#ifdef MVR_NO_TUNING
+#define MVR_SETPRIO(p) ((void)0)
+#define MVR_SLEEP(n) ((void)0)
+#else
+#define MVR_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#define MVR_SLEEP(n) __builtin_amdgcn_s_sleep(n)
+#endif
+
 // The sections, in dependency order (one translation unit):
 #include "mvr_cameras.inc"
 #include "mvr_mesh_prepass.inc"

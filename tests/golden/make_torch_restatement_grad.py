@@ -85,7 +85,28 @@ def phong_diff(p2f, bary, verts, faces, normals, cam_center, light_dir, obj, bg)
     ambient = torch.tensor([1.0, 1.0, 1.0]) * torch.tensor([0.5, 0.5, 0.5])
     colors = (ambient + diffuse) * texels + specular
     out = torch.where(mask[..., None], colors, torch.tensor(bg)[None, None, :])
-    return out.permute(2, 0, 1)
+    # (second value: the pixels on a KINK of the diffuse term — covered, |n . l| < KINK —, where an fp32 evaluation may take the
+    # other branch of relu(n . l) than this float64 one)
+    return out.permute(2, 0, 1), (mask & (cos_angle.detach().abs() < KINK))
+
+
+KINK = 1e-5
+# Round 5: the pixels of nearly EDGE-ON winning faces.  cond = (larger extent of the face's NDC box)^2 / |2 x NDC area| is ~1-2 for a
+# well-shaped face and grows like 1 / foreshortening; a pixel's term of d loss / d angle contains d barycentrics / d vertex ~ 1 / area,
+# so a handful of pixels on such faces carry terms 100-1000 x the typical one, and an fp32 evaluation of THEIR edge functions is what
+# the fp32 kernels differ by from this float64 pass (not relu kinks: no covered pixel of the c3 case has |n . l| < 1e-5).  The
+# fixture therefore also holds, per threshold, the bit mask of the pixels with cond > threshold and the gradients of the loss
+# without them.
+COND_THRESHOLDS = (30.0, 100.0, 300.0, 1000.0)
+
+
+def face_condition(ndc32, faces, p2f):
+    fv = ndc32[faces][p2f.clamp(min=0)]                                 # (S, S, 3 corners, 3)
+    x, y = fv[..., 0], fv[..., 1]
+    ext = torch.maximum(x.max(-1).values - x.min(-1).values, y.max(-1).values - y.min(-1).values)
+    area2 = ((x[..., 1] - x[..., 0]) * (y[..., 2] - y[..., 0]) - (x[..., 2] - x[..., 0]) * (y[..., 1] - y[..., 0])).abs()
+    cond = ext * ext / area2.clamp(min=1e-30)
+    return torch.where(p2f >= 0, cond, torch.zeros_like(cond))
 
 
 def _project(verts, faces, a, e, d, V):
@@ -106,6 +127,7 @@ def render_views_diff(verts, faces, az, el, di, S, relative_light, g_seed):
     with torch.no_grad():
         ndc32, _ = _project(verts, faces, *(torch.from_numpy(np.asarray(x, np.float32)) for x in (az, el, di)), V)
         p2f_all = [r1.rasterize(ndc32[n], faces, S)[0] for n in range(V)]
+        cond_all = [face_condition(ndc32[n], faces, p2f_all[n]).double() for n in range(V)]
     torch.set_default_dtype(torch.float64)
     try:
         vd = verts.double()
@@ -117,17 +139,27 @@ def render_views_diff(verts, faces, az, el, di, S, relative_light, g_seed):
         obj = bg = (float(np.float32(0.99999)),) * 3
         G = torch.from_numpy(np.random.default_rng(g_seed).standard_normal((V, 3, S, S)).astype(np.float32)).double()
         loss = torch.zeros(())
-        img_all = []
+        loss_m = torch.zeros(())   # the same loss without the pixels on a kink of relu(n . l) (round 5)
+        loss_c = [torch.zeros(()) for _ in COND_THRESHOLDS]   # ... and without the pixels of badly conditioned (edge-on) faces
+        img_all, kink_all = [], []
         for n in range(V):
             bary = bary_of_winners(ndc[n], faces, p2f_all[n])
             light = lights[n] if relative_light else torch.tensor([0.0, 1.0, 0.0])
-            img = phong_diff(p2f_all[n], bary, vd, faces, nrm, centers[n], light, obj, bg)
+            img, kink = phong_diff(p2f_all[n], bary, vd, faces, nrm, centers[n], light, obj, bg)
             loss = loss + (img * G[n]).sum()
+            loss_m = loss_m + (img * G[n] * (~kink)[None].to(img.dtype)).sum()
+            for k, thr in enumerate(COND_THRESHOLDS):
+                loss_c[k] = loss_c[k] + (img * G[n] * (cond_all[n] <= thr)[None].to(img.dtype)).sum()
             img_all.append(img.detach())
-            print("  view", n, "covered", float((p2f_all[n] >= 0).double().mean()), flush=True)
+            kink_all.append(kink)
+            print("  view", n, "covered", float((p2f_all[n] >= 0).double().mean()), "pixels on a kink", int(kink.sum()), flush=True)
+        gm = torch.autograd.grad(loss_m, (a, e, d), retain_graph=True)
+        gc = [[g.numpy().copy() for g in torch.autograd.grad(lc, (a, e, d), retain_graph=True)] for lc in loss_c]
+        cond_bits = [np.packbits((torch.stack(cond_all) > thr).numpy(), axis=-1) for thr in COND_THRESHOLDS]
         loss.backward()
         out = (torch.stack(p2f_all).numpy().astype(np.int16), torch.stack(img_all).numpy(),
-               a.grad.numpy().copy(), e.grad.numpy().copy(), d.grad.numpy().copy())
+               a.grad.numpy().copy(), e.grad.numpy().copy(), d.grad.numpy().copy(),
+               np.packbits(torch.stack(kink_all).numpy(), axis=-1), [g.numpy().copy() for g in gm], cond_bits, gc)
     finally:
         torch.set_default_dtype(torch.float32)
     return out
@@ -149,21 +181,33 @@ def main(which):
     if "c1" in which:
         v, f = syn.synthetic_mesh("M", 0)
         az, el, di = syn.circular_views(4, 30.0, 2.2)
-        p2f, img, ga, ge, gd = render_views_diff(torch.from_numpy(v), torch.from_numpy(f), az, el, di, 128, False, 101)
+        p2f, img, ga, ge, gd = render_views_diff(torch.from_numpy(v), torch.from_numpy(f), az, el, di, 128, False, 101)[:5]
         out.update(c1_azim=az, c1_elev=el, c1_dist=di, c1_pix_to_face=p2f, c1_grad_azim=ga, c1_grad_elev=ge, c1_grad_dist=gd,
                    c1_g_seed=np.array(101), c1_image_size=np.array(128), c1_image_sum=np.array(img.astype(np.float64).sum()))
         print("c1 grads", ga, ge, gd)
     if "c3" in which:
         B, V, S = 2, 12, 224
         az, el, di = c3_views(B, V, 1)
-        p2fs, gas, ges, gds, sums = [], [], [], [], []
+        p2fs, gas, ges, gds, sums, kinks, gms, cbits, gcs = [], [], [], [], [], [], [], [], []
         for b in range(B):
             v, f = syn.synthetic_mesh("M", b)
-            p2f, img, ga, ge, gd = render_views_diff(torch.from_numpy(v), torch.from_numpy(f), az[b], el[b], di[b], S, True, 200 + b)
+            p2f, img, ga, ge, gd, kink, gm, cb, gc = render_views_diff(torch.from_numpy(v), torch.from_numpy(f), az[b], el[b], di[b], S, True, 200 + b)
+            cbits.append(cb); gcs.append(gc)
             p2fs.append(p2f); gas.append(ga); ges.append(ge); gds.append(gd); sums.append(img.astype(np.float64).sum())
+            kinks.append(kink); gms.append(gm)
         out.update(c3_azim=az, c3_elev=el, c3_dist=di, c3_pix_to_face=np.stack(p2fs), c3_grad_azim=np.stack(gas),
                    c3_grad_elev=np.stack(ges), c3_grad_dist=np.stack(gds), c3_g_seeds=np.array([200, 201]), c3_image_size=np.array(S),
-                   c3_mesh_seeds=np.array([0, 1]), c3_image_sum=np.array(sums))
+                   c3_mesh_seeds=np.array([0, 1]), c3_image_sum=np.array(sums),
+                   # the pixels with |n . l| < KINK (bit-packed along the columns) and the gradients of the loss WITHOUT them
+                   c3_kink_bits=np.stack(kinks), c3_kink_threshold=np.array(KINK),
+                   c3_grad_azim_nokink=np.stack([g[0] for g in gms]), c3_grad_elev_nokink=np.stack([g[1] for g in gms]),
+                   c3_grad_dist_nokink=np.stack([g[2] for g in gms]),
+                   # per threshold t: the pixels whose winning face has cond > t (face_condition; bit-packed), the gradients without them
+                   c3_cond_thresholds=np.array(COND_THRESHOLDS),
+                   c3_cond_bits=np.stack([np.stack([cbits[b][k] for b in range(B)]) for k in range(len(COND_THRESHOLDS))]),
+                   c3_grad_azim_cond=np.stack([np.stack([gcs[b][k][0] for b in range(B)]) for k in range(len(COND_THRESHOLDS))]),
+                   c3_grad_elev_cond=np.stack([np.stack([gcs[b][k][1] for b in range(B)]) for k in range(len(COND_THRESHOLDS))]),
+                   c3_grad_dist_cond=np.stack([np.stack([gcs[b][k][2] for b in range(B)]) for k in range(len(COND_THRESHOLDS))]))
         print("c3 grads", np.stack(gas), np.stack(ges), np.stack(gds))
     path = os.path.join(HERE, "torch_restatement_grad.npz")
     if os.path.exists(path):   # a partial run keeps the other case

@@ -563,3 +563,61 @@ def test_oracle_finite_differences_against_torch_autograd_c1(oracle):
         rel = np.abs(fd - ref).max() / np.abs(ref).max()
         print("%s: oracle FD vs torch autograd, max relative error %.2e (|grad| up to %.3g)" % (name, rel, np.abs(ref).max()))
         assert rel <= 1e-4, (name, fd, ref)   # (observed: 6e-6 ... 1.5e-5)
+
+
+def test_oracle_against_torch_restatement_on_cad_and_ragged_meshes(oracle):
+    """Round 5: the torch-made second implementation (tests/golden/make_torch_restatement_r5.py: real fp32
+    torch ops in PyTorch3D's op order, a naive (z, face index) rasteriser) on a CAD-like object — two-triangle flat sides, slivers,
+    coincident reversed shells — and on a ragged tier-S / tier-M pair: pixel -> face maps identical (the tie rule of SURVEY A.4 on
+    the coincident shells included), images within 1e-4 on every pixel whose face touches no cancelled vertex normal (the fixture
+    sums normals with a float32 index_add: noise there, see orc_vertex_normals)."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "torch_restatement_r5.npz"))
+    from mvtn_amd import synthetic as syn
+    v, f = syn.cad_mesh(int(fx["cad_seed"]), n_faces=int(fx["cad_faces"]))
+    S = int(fx["cad_image_size"])
+    got = oracle.render_meshes([v], [f], fx["cad_azim"][None], fx["cad_elev"][None], fx["cad_dist"][None], S,
+                               obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, mode=1)
+    want_map = fx["cad_pix_to_face"].astype(np.int32)
+    differ = got["pix_to_face"] != want_map
+    n_diff = int(differ.sum())
+    # Where the two differ, BOTH name a face of the same coincident pair (identical vertex positions, opposite winding): which
+    # twin has the smaller interpolated depth is decided in its last bit, and the fixture projects the vertices through 4 x 4 bmm
+    # chains (PyTorch3D's transform_points) while the oracle / the library use the closed form — the vertices differ in the last bit.
+    # Not a difference of the tie RULE: of the input it is applied to (and one more reason why parity is "unpinned", DESIGN 4).
+    twin_key = lambda i: tuple(sorted(map(tuple, v[f[i]].tolist())))   # noqa: E731
+    n_twin = sum(1 for x, y in zip(got["pix_to_face"][differ], want_map[differ]) if x >= 0 and y >= 0 and twin_key(x) == twin_key(y))
+    print("cad: %d of %d covered pixels on another face, %d of them on the face's coincident twin" % (n_diff, (want_map >= 0).sum(), n_twin))
+    assert n_diff == n_twin and n_diff <= 0.05 * (want_map >= 0).sum()
+    face_c = oracle.cancelled_normal_vertices(v, f)[f].any(axis=1)
+    touch = np.where(want_map >= 0, face_c[np.maximum(want_map, 0)], False)
+    d = np.abs(got["images"][0] - fx["cad_images"]).max(axis=1)
+    ok = ~touch & ~differ
+    assert touch.sum() > 100 and d[ok].max() <= 1e-4, (touch.sum(), d[ok].max())
+    for name, tier, seed in (("rag_s", "S", int(fx["rag_seeds"][0])), ("rag_m", "M", int(fx["rag_seeds"][1]))):
+        vr, fr = syn.synthetic_mesh(tier, seed)
+        g = oracle.render_meshes([vr], [fr], fx["rag_azim"][None], fx["rag_elev"][None], fx["rag_dist"][None], int(fx["rag_image_size"]),
+                                 obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, mode=1)
+        assert (g["pix_to_face"] != fx[name + "_pix_to_face"].astype(np.int32)).sum() == 0, name
+        assert np.abs(g["images"][0] - fx[name + "_images"]).max() <= 1e-4, name
+
+
+def test_oracle_normal_sum_switch_changes_only_cancelled_vertices(oracle):
+    """Switch #4 (set_normals_exact_sum): on a lumpy icosphere nothing cancels and the two sums agree to ~1e-6 in the colours; on a
+    CAD-like mesh every pixel that moves by more than 1e-4 lies on a face touching a vertex whose face normals cancel."""
+    from mvtn_amd import synthetic as syn
+    az, el, di = (x[None, :4] for x in syn.spherical_views(12))
+    for mesh, expect_cancelled in ((syn.synthetic_mesh("S", 0), False), (syn.cad_mesh(0, n_faces=1280), True)):
+        v, f = mesh
+        a = oracle.render_meshes([v], [f], az, el, di, 96, mode=1)
+        oracle.set_normals_exact_sum(True)
+        try:
+            b = oracle.render_meshes([v], [f], az, el, di, 96, mode=1)
+        finally:
+            oracle.set_normals_exact_sum(False)
+        assert np.array_equal(a["pix_to_face"], b["pix_to_face"])
+        d = np.abs(a["images"] - b["images"])[0].max(axis=1)
+        canc = oracle.cancelled_normal_vertices(v, f)
+        assert canc.any() == expect_cancelled
+        touch = np.where(a["pix_to_face"] >= 0, canc[f].any(axis=1)[np.maximum(a["pix_to_face"], 0)], False)
+        assert d[~touch].max() <= 1e-5, d[~touch].max()
