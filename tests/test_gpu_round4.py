@@ -74,8 +74,8 @@ def test_backward_kernels_against_torch_autograd_c3(gather):
     grads, p2f = _hip_grads(list(vl), list(fl), az, el, di, S, G, True, gather)
     differ = p2f.reshape(2, 12, S, S) != fx["c3_pix_to_face"].astype(np.int32)
     # (the torch rasteriser works on bmm-projected vertices: a last-bit difference of a vertex may move an edge pixel; a pixel
-    # that changes face changes the function by one pixel's worth, far below the tolerance)
-    assert differ.sum() <= 8, differ.sum()
+    # that changes face changes the function by one pixel's worth.  Observed, and asserted: ONE pixel, in view 11 of object 0)
+    assert differ.sum() == 1 and differ[0, 11].sum() == 1, differ.reshape(24, -1).sum(1)
     # a view that holds such a pixel differentiates a (one pixel) different function: its three derivatives are compared with a
     # loose bound, every other view with the tight one
     dirty = differ.reshape(24, -1).any(1).reshape(2, 12)
@@ -85,13 +85,47 @@ def test_backward_kernels_against_torch_autograd_c3(gather):
         clean = err[~dirty].max()
         print("c3 %s (%s): max relative error %.2e over the %d views with identical maps (%.2e over the %d with a pixel on another face)" % (
             name, "gather" if gather else "table", clean, int((~dirty).sum()), err[dirty].max() if dirty.any() else 0.0, int(dirty.sum())))
-        # (fp32 kernels against a float64 derivative: with the relative light the diffuse term's relu kinks lie on the silhouette
-        # of every view, and a pixel whose n . l is +-1e-7 takes the other branch in fp32 — its whole term (times a unit-variance
-        # G) is the difference.  Observed: <= 2.6e-3 at one view, <= 1e-3 at the others; the oracle's fp64 central differences
-        # agree with the same fixture to 3e-5, tests/test_oracle.py / tools: the semantics are pinned there)
+        # fp32 kernels against a float64 derivative: <= 3.3e-3 at one view, <= 1.5e-3 at a second, <= 4e-4 elsewhere.  Round 4
+        # blamed relu kinks of the diffuse term; round 5 measured it: NO covered pixel of this case has |n . l| < 1e-5 (the
+        # fixture counts them).  What the outliers are is the next test: a few dozen pixels on nearly edge-on faces.
         assert clean <= 5e-3, (name, clean)
         assert (err[~dirty] > 2e-3).sum() <= 2, (name, err)
         assert err.max() <= 3e-2, (name, err.max())
+
+
+@pytest.mark.parametrize("gather", [False, True], ids=["table_kernel", "gather_kernel"])
+def test_backward_outliers_are_the_pixels_of_edge_on_faces(gather):
+    """what the 2 of 72 C3 derivatives that miss 2e-3 (previous test) come from.  The fixture holds, per
+    threshold t, the bit mask of the pixels whose winning face is badly conditioned — cond = (larger extent of its NDC box)^2 /
+    |2 x NDC area| > t: nearly edge-on, the barycentrics' derivative ~ 1 / area — and torch.autograd's gradients of the loss WITHOUT
+    those pixels.  With the same mask on the upstream gradient the fp32 kernels agree with float64 autograd to <= 2e-4 on every
+    derivative of every view with an identical pixel -> face map once the 40 pixels with cond > 100 (0.008 % of the covered
+    ones) are out; with only the 4 pixels of cond > 300 out, 7 derivatives still miss 2e-4; with 1 pixel out, 12.  (And no
+    pixel sits on a kink of relu(n . l): `c3_kink_bits` is empty, the masked and unmasked gradients are equal bit for bit.)"""
+    fx = _fx("torch_restatement_grad.npz")
+    if "c3_cond_bits" not in fx:
+        pytest.skip("fixture without the conditioning masks")
+    assert np.unpackbits(fx["c3_kink_bits"]).sum() == 0
+    for k in ("azim", "elev", "dist"):
+        assert np.array_equal(fx["c3_grad_" + k], fx["c3_grad_" + k + "_nokink"])
+    S = int(fx["c3_image_size"])
+    az, el, di = (fx["c3_" + k].astype(np.float32) for k in ("azim", "elev", "dist"))
+    vl, fl = zip(*[syn.synthetic_mesh("M", int(s)) for s in fx["c3_mesh_seeds"]])
+    G = np.stack([np.random.default_rng(int(s)).standard_normal((12, 3, S, S)).astype(np.float32) for s in fx["c3_g_seeds"]])
+    thr = [float(t) for t in fx["c3_cond_thresholds"]]
+    over = {}
+    for k, t in enumerate(thr):
+        mask = np.unpackbits(fx["c3_cond_bits"][k], axis=-1)[..., :S].astype(bool)      # (2, 12, S, S): cond > t
+        grads, p2f = _hip_grads(list(vl), list(fl), az, el, di, S, G * (~mask)[:, :, None], True, gather)
+        dirty = (p2f.reshape(2, 12, S, S) != fx["c3_pix_to_face"].astype(np.int32)).reshape(24, -1).any(1).reshape(2, 12)
+        err = np.stack([np.abs(got - fx["c3_grad_%s_cond" % name][k].astype(np.float64)) / np.abs(fx["c3_grad_%s_cond" % name][k]).max()
+                        for name, got in zip(("azim", "elev", "dist"), grads)])
+        over[t] = int((err[:, ~dirty] > 2e-4).sum())
+        print("cond > %g masked: %d pixels; derivatives of clean views above 2e-4: %d of %d; max %.2e (dirty view: %.2e)" % (
+            t, mask.sum(), over[t], 3 * (~dirty).sum(), err[:, ~dirty].max(), err[:, dirty].max()))
+        if t <= 100.0:
+            assert over[t] == 0 and err[:, dirty].max() <= 2e-3, (t, err)
+    assert over[1000.0] >= over[300.0] > 0     # the fewer of those pixels are masked, the more derivatives miss the bound
 
 
 @pytest.mark.parametrize("S", [96, 95])

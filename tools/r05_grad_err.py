@@ -19,3 +19,18 @@ for gather in (False, True):
         ref = fx["c3_grad_" + name].astype(np.float64)
         print(name, "ref max %.1f; |err| / max|ref| x 1e4:\n" % np.abs(ref).max(), 1e4 * np.abs(got - ref) / np.abs(ref).max())
 print("elev:\n", el, "\nazim:\n", az)
+
+# ---- round 5: the same comparison with the pixels of badly conditioned (edge-on) faces masked out of the loss on both sides
+if "c3_cond_bits" in fx:
+    thr = fx["c3_cond_thresholds"]
+    for k, t in enumerate(thr):
+        mask = np.unpackbits(fx["c3_cond_bits"][k], axis=-1)[..., :S].astype(bool)      # (2, 12, S, S): cond > t
+        Gm = G * (~mask)[:, :, None]
+        grads, p2f = t4._hip_grads(list(vl), list(fl), az, el, di, S, Gm, True, False)
+        errs = []
+        for i, (name, got) in enumerate(zip(("azim", "elev", "dist"), grads)):
+            ref = fx["c3_grad_%s_cond" % name][k].astype(np.float64)
+            errs.append(np.abs(got - ref) / np.abs(ref).max())
+        e = np.stack(errs)
+        print("cond > %g masked (%d pixels, %.3f %% of the covered): max rel err %.2e; derivatives > 2e-4: %d of 72; worst views %s" % (
+            t, mask.sum(), 100.0 * mask.sum() / (fx["c3_pix_to_face"] >= 0).sum(), e.max(), (e > 2e-4).sum(), np.argwhere(e > 2e-4).tolist()[:6]))
