@@ -1370,7 +1370,7 @@ def test_fast_rasteriser_equals_exact_kernel(name, specs, V, size, dist, jitter)
     assert np.abs(out["fast"][0] - out["exact"][0]).max() <= 5e-5
     if "soup" not in str(specs) and dist >= 1.6:   # (nearer than 1.5 the clip plane z = 0.5 cuts faces: those views take the exact path)
         assert out["fast"][2] <= n_strips // 100, "ordinary meshes should almost never need the exact path"
-    if "soup" in str(specs):
+    if "soup" in str(specs) and size % 2 == 0:   # (odd widths take the exact kernel: nothing to settle)
         # coincident double-sided faces: undecidable for the affine depth keys.  Rounds 2-4 handed such strips to the exact kernel's
         # body; round 5 settles the recorded (pixel, face) candidates inside the fast kernel (mvr_mesh_fast_stats counts them)
         _, _, st = F.render_meshes_fragments(packed, R, T, light, F.mesh_params(V, size, 1, obj, bg), return_stats=True)
