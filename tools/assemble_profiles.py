@@ -23,7 +23,7 @@ def pmc(dirn, kern):
     return vals
 
 
-for w in ("mesh_fwd", "mesh_fwdbwd", "points_fwd", "c5_per_gpu", "c5", "soft_fwdbwd"):
+for w in ("mesh_fwd", "mesh_fwdbwd", "points_fwd", "c5_per_gpu", "c5", "soft_fwdbwd", "geo_cad", "geo_ragged"):
     fs = glob.glob("%s/stats_%s/**/*kernel_stats.csv" % (src, w), recursive=True)
     if not fs:
         print(w, "(no kernel stats)")
