@@ -27,9 +27,11 @@ for case in range(n_cases):
     cull = bool(rng.integers(0, 4) == 0)
     vl, fl = [], []
     for b in range(B):
-        kind = rng.integers(0, 4)
+        kind = rng.integers(0, 6)
         if kind == 0:
             v, f = syn.cad_soup(int(rng.integers(0, 1000)))
+        elif kind >= 4:   # round 5: CAD-like assemblies (big flat triangles, slivers, coincident reversed shells, interior parts)
+            v, f = syn.cad_mesh(int(rng.integers(0, 1000)), n_faces=int(rng.choice([320, 1280, 5120])), double_sided=float(rng.choice([0.0, 0.3, 0.6])))
         else:
             v, f = syn.synthetic_mesh(str(rng.choice(["S", "M", "M", "L"])), int(rng.integers(0, 1000)))
         v = v * rng.uniform(0.5, 1.3, 3).astype(np.float32) + rng.uniform(-0.2, 0.2, 3).astype(np.float32)
@@ -39,6 +41,7 @@ for case in range(n_cases):
     di = rng.uniform(0.9, 3.0, (B, V)).astype(np.float32)
     obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
     zc = 0.5 if (persp and rng.integers(0, 2)) else 0.0   # PyTorch3D >= 0.5's face clipping (cuts faces when dist < ~1.5)
+    oracle.set_normals_exact_sum(True)   # (the library's sums: coincident shells on shared vertices have normals that cancel — a float sum there is noise of its order)
     want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, perspective_correct=persp, cull_backfaces=cull, mode=1,
                                 z_clip=zc)
     packed = PackedMeshes.from_meshes(Meshes(vl, fl), dev)
