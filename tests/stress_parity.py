@@ -1,6 +1,6 @@
 """Manual stress run (not collected by pytest): random meshes / views / image sizes / strip heights through the C ABI
 against the oracle — bit-exact pixel->face maps, pixel tolerance on well-conditioned pixels.
-    python tests/stress_parity.py [n_cases] [seed]"""
+    python tests/stress_parity.py [n_cases] [seed] [first_case]      (first_case: the cases before it are only drawn, not run)"""
 import os
 import sys
 
@@ -16,6 +16,7 @@ from mvtn_amd.structures import Meshes, PackedMeshes  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = torch.device("cuda:0")
 oracle.set_threads(8)
 bad = 0
@@ -41,6 +42,8 @@ for case in range(n_cases):
     di = rng.uniform(0.9, 3.0, (B, V)).astype(np.float32)
     obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
     zc = 0.5 if (persp and rng.integers(0, 2)) else 0.0   # PyTorch3D >= 0.5's face clipping (cuts faces when dist < ~1.5)
+    if case < first_case:
+        continue
     oracle.set_normals_exact_sum(True)   # (the library's sums: coincident shells on shared vertices have normals that cancel — a float sum there is noise of its order)
     want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, perspective_correct=persp, cull_backfaces=cull, mode=1,
                                 z_clip=zc)

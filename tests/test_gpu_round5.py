@@ -219,6 +219,29 @@ def test_hip_against_torch_restatement_on_cad_and_ragged_meshes(oracle):
         assert np.abs(img[b] - fx[name + "_images"]).max() <= 1e-4, name
 
 
+def test_untrusted_face_over_the_left_image_border(oracle):
+    """Round 5, found by tests/stress_parity.py as a GPU memory fault: a face of infinite tolerance (a nonzero edge coefficient below
+    2^-44: every pixel it touches is settled exactly) reports BOTH pixels of every pair — also the second pixel of a pair that starts
+    in the image's last column, which does not exist.  At pixel 0 of a strip that was index -1; the candidate list read it as pixel
+    8191 of list entry 2^19 and gathered from there.  Eight meshes whose big, nearly-axis-aligned triangle is shifted pixel by pixel
+    across the left border (either parity of its first column), two image sizes: maps bit-exact against the oracle."""
+    for S in (96, 64):
+        vl, fl = [], []
+        for k in range(16):
+            dx = (k % 8) * 2.2 * 2.0 / (S * 1.7320508)    # one pixel per step at the depth of the big triangle
+            sx = 1.0 if k < 8 else -1.0                    # (both borders: image column 0 is the one the fault needed)
+            v = np.array([[sx * (-0.9 + dx), 0.0, 0.1], [sx * 3.0, 1e-20, 0.1], [sx * 3.0, 0.9, 0.1],   # beyond the border; one edge with dy = 1e-20 (a coefficient of ~1e-20: not trusted)
+                          [-0.5, -0.5, -0.3], [0.5, -0.5, -0.3], [0.0, 0.6, -0.3]], np.float32)     # an ordinary triangle behind it
+            vl.append(v); fl.append(np.array([[0, 1, 2], [3, 4, 5]], np.int64))
+        az, el, di = np.zeros((16, 1), np.float32), np.zeros((16, 1), np.float32), np.full((16, 1), 2.2, np.float32)
+        want = oracle.render_meshes(vl, fl, az, el, di, S, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, mode=1)
+        img, p2f, st = _render(vl, fl, az, el, di, S)
+        assert (want["pix_to_face"][:, :, 0] == 0).any() and (want["pix_to_face"][:, :, S - 1] == 0).any()   # the big triangle reaches both borders
+        assert (p2f != want["pix_to_face"]).sum() == 0, S
+        assert np.abs(img - want["images"]).max() <= 1e-4
+        assert st[1] > 0                                           # its pixels went through the exact settle
+
+
 _TUNING_SCRIPT = r"""
 import sys
 import numpy as np
