@@ -30,8 +30,12 @@ lib.mvr_diag_set_buffer.argtypes = [ctypes.c_void_p]
 lib.mvr_diag_set_buffer(buf.data_ptr())
 r(packed, None, ta, te, td)
 torch.cuda.synchronize()
-d = buf.cpu().numpy().reshape(-1, 8)[:nblocks].astype(np.float64)
-d = d[d[:, 5] > 0]
+raw = buf.cpu().numpy().reshape(-1, 8)[:nblocks]
+raw = raw[raw[:, 5] > 0]
+d = raw.astype(np.float64)
+d[:, 6] = raw[:, 6] & 0xffffffff
+d[:, 7] = raw[:, 7] & 0xffffffff
+n_wide, n_fat = (raw[:, 6] >> 32).astype(np.float64), (raw[:, 7] >> 32).astype(np.float64)
 tot = d[:, 5] - d[:, 0]
 print("workgroups with work: %d   cycles/workgroup mean %.0f max %.0f; listed faces mean %.0f; ambiguous pixels total %d" % (
     len(d), tot.mean(), tot.max(), d[:, 6].mean(), d[:, 7].sum()))
@@ -57,3 +61,13 @@ if len(rs):
     print("resolve+shade phases (wave 0 stamps), workgroups %d: covered px mean %.0f, winner faces mean %.0f max %.0f" % (len(rs), rs[:, 6].mean(), rs[:, 7].mean(), rs[:, 7].max()))
     for nme, a_, b_ in [("scan + bg stores + flags", 0, 1), ("prefix", 1, 2), ("winner list", 2, 3), ("table build (gathers)", 3, 4), ("shade", 4, 5)]:
         print("  %-28s mean %7.0f cycles" % (nme, (rs[:, b_] - rs[:, a_]).mean()))
+
+# what makes a strip heavy (round 5, CAD-like batches): least-squares cost per listed face / wide entry / whole-wave entry / candidate
+X = np.stack([np.ones_like(tot), d[:, 6], n_wide - n_fat, n_fat, d[:, 7]], 1)
+coef, *_ = np.linalg.lstsq(X, tot, rcond=None)
+print("cycles ~ %.0f + %.1f per listed face + %.1f per thin wide entry + %.1f per whole-wave entry + %.2f per candidate" % tuple(coef))
+print("shares of the summed cycles: base %.1f %%, listed %.1f %%, thin wide %.1f %%, whole-wave %.1f %%, candidates %.1f %%" % tuple(100 * coef * X.sum(0) / tot.sum()))
+order = np.argsort(-tot)[:12]
+print("heaviest strips: cycles | listed, thin wide, whole-wave, candidates | init, raster(w0), wait, settle+resolve")
+for i in order:
+    print("  %7.0f | %5.0f %5.0f %5.0f %6.0f | %6.0f %7.0f %7.0f %7.0f" % (tot[i], d[i, 6], n_wide[i] - n_fat[i], n_fat[i], d[i, 7], spans[0][i], spans[1][i], spans[2][i], spans[3][i]))
