@@ -242,6 +242,36 @@ def test_untrusted_face_over_the_left_image_border(oracle):
         assert st[1] > 0                                           # its pixels went through the exact settle
 
 
+
+@pytest.mark.parametrize("size,strip,layers,redone", [(224, 0, 2, False), (224, 0, 6, True), (256, 16, 2, True), (256, 8, 2, False)])
+def test_stacks_of_coincident_faces_fill_the_candidate_area(oracle, size, strip, layers, redone):
+    """`layers` copies of one nearly frame-filling quad on top of each other, every second one with reversed winding (the (z, face index) tie
+    rule decides every pixel), a small triangle in front.  Two copies: every pixel of a strip is a candidate of the fast rasteriser's
+    exact settle, reserved by the waves' ballots (one LDS atomic per wave), compacted into the LDS work list.  Six copies: more
+    candidates than the strip's area of the workspace holds (2 per pixel).  256 pixels wide in 16-row strips: two copies already
+    leave more than the work list in LDS holds (3072 + 256 x 16 entries < 2 x 16 x 256; in 8-row strips it fits).  Those strips are
+    redone by the exact body in the same launch.  Maps
+    bit-exact against the oracle either way."""
+    q = np.array([[-1.25, -1.25, 0.0], [1.25, -1.25, 0.0], [1.25, 1.25, 0.0], [-1.25, 1.25, 0.0]], np.float32)   # (every vertex in front of the clip plane in all three views)
+    verts = [q for _ in range(layers)] + [np.array([[-0.3, -0.3, -0.4], [0.3, -0.3, -0.4], [0.0, 0.4, -0.4]], np.float32)]
+    faces = []
+    for k in range(layers):
+        o = 4 * k
+        faces += [[o, o + 1, o + 2], [o, o + 2, o + 3]] if k % 2 == 0 else [[o, o + 2, o + 1], [o, o + 3, o + 2]]
+    faces.append([4 * layers, 4 * layers + 1, 4 * layers + 2])
+    v, f = np.concatenate(verts, 0), np.asarray(faces, np.int64)
+    az, el, di = np.array([[0.0, 30.0, 180.0]], np.float32), np.array([[0.0, 20.0, -10.0]], np.float32), np.full((1, 3), 2.2, np.float32)
+    kw = dict(strip_rows=strip) if strip else {}
+    want = oracle.render_meshes([v], [f], az, el, di, size, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, mode=1)
+    img, p2f, st = _render([v], [f], az, el, di, size, **kw)
+    assert (p2f != want["pix_to_face"]).sum() == 0
+    assert (p2f >= 0).mean() > 0.6 and len(np.unique(p2f[0])) >= 3
+    assert np.abs(img - want["images"]).max() <= 1e-4
+    assert (st[0] > 0) == redone, st          # strips redone by the exact body
+    if not redone:
+        assert st[1] > 0.5 * (p2f >= 0).sum()  # candidates of the settle: about one per covered pixel and pair of copies
+
+
 _TUNING_SCRIPT = r"""
 import sys
 import numpy as np
