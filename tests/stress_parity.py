@@ -22,8 +22,8 @@ oracle.set_threads(8)
 bad = 0
 for case in range(n_cases):
     B, V = int(rng.integers(1, 4)), int(rng.integers(1, 5))
-    size = int(rng.choice([32, 45, 64, 96, 100, 128, 224]))
-    strip = int(rng.choice([0, 0, 0, 3, 5, 8]))
+    size = int(rng.choice([32, 45, 64, 96, 100, 128, 224, 256]))   # (256: the widest image of the fast rasteriser)
+    strip = int(rng.choice([0, 0, 0, 3, 5, 8, 16]))                   # (16 rows x 256: the settle's LDS work list is the smaller bound)
     persp = bool(rng.integers(0, 2))
     cull = bool(rng.integers(0, 4) == 0)
     vl, fl = [], []
