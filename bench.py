@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--host-meshes", action="store_true", help="hand CPU meshes to every step (the reference's interface): packing + H2D inside the timed region; documentation only, never the headline")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world size 1 (self-test of the N>1 code path)")
     ap.add_argument("--cpu-views", type=int, default=16, help="views in the cpu_baseline sample (~0.7 s each for meshes)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block (the other workloads measured after the headline in the driver's command)")
+    ap.add_argument("--secondary-steps", type=int, default=500, help="timed steps of each `secondary` workload (behind 100 untimed ones; the fixed ~0.6 ms around a timed region is 6 us per step at 100 steps)")
     ap.add_argument("--ref-n1", action="store_true",
                     help="N > 1, workload c5: rank 0 also renders the WHOLE workload (all 64 objects) alone, after the timed regions, and "
                          "the line carries `scaling_vs_one_gpu` — speed-up and efficiency of the N-GPU run against that one-GPU reference, "
@@ -137,6 +140,136 @@ def cpu_baseline(args, V):
                                     "note": "the same loop with OpenMP over the image rows of one view at a time (SURVEY 8d ii); upstream's CPU "
                                             "rasteriser is single-threaded — `value` above is the baseline"}
     return base
+
+
+SECONDARY = {   # name -> (workload, geometry, tier, B, V): every BASELINE config the headline (C2 on icospheres) does not time
+    "cad": ("mesh_fwd", "cad", "M", 16, 12),            # configs[1] on the geometry class the reference renders (ModelNet40: CAD models)
+    "ragged": ("mesh_fwd", "ragged", "M", 16, 12),      # configs[1], ragged tier-S / M / L / M batch
+    "c3_fwdbwd": ("mesh_fwdbwd", "ico", "M", 16, 12),   # configs[2]
+    "c4_points": ("points_fwd", "ico", "M", 20, 20),    # configs[3]
+    "c5_per_gpu": ("mesh_fwd", "ico", "L", 8, 20),      # configs[4]: one GPU's share at N = 8
+}
+
+
+def measure_secondary(name, dev, lib, H, steps, untimed, with_oracle, rotation_check="device"):
+    """One workload of the `secondary` block: the same step as the headline's (MVRenderer.forward [+ backward]) on other inputs,
+    `untimed` steps, then `steps` timed ones between two synchronisations, then the dominant kernel's HIP-event time over `steps`
+    more, the fast rasteriser's statistics and a bounded parity check against the oracle (the checker, never the thing timed)."""
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes, synthetic as syn
+    workload, geometry, tier, B, V = SECONDARY[name]
+    W = H
+    P = 2048
+    az, el, di = syn.spherical_views(V)
+    if workload == "points_fwd":
+        di = np.full(V, 1.0, np.float32)
+    azim, elev, dist_t = (torch.from_numpy(np.tile(x, (B, 1))).to(dev) for x in (az, el, di))
+    nv_list, nf_list, vl, fl = [], [], [], []
+    points = packed = None
+    if workload == "points_fwd":
+        clouds = []
+        for i in range(B):
+            v, f = syn.synthetic_mesh(tier, i)
+            clouds.append(syn.surface_points(v, f, P, seed=i))
+        points = torch.from_numpy(np.stack(clouds)).to(dev)
+        renderer = MVRenderer(V, H, pc_rendering=True, object_color="white", background_color="white", points_radius=0.006,
+                              rotation_check=rotation_check).eval()
+    else:
+        for i in range(B):
+            v, f = syn.geometry_mesh(geometry, tier, i)
+            vl.append(torch.from_numpy(v)); fl.append(torch.from_numpy(f))
+            nv_list.append(len(v)); nf_list.append(len(f))
+        packed = PackedMeshes.from_meshes(Meshes(vl, fl), dev)
+        renderer = MVRenderer(V, H, pc_rendering=False, object_color="white", background_color="white",
+                              light_direction="relative" if workload == "mesh_fwdbwd" else "fixed", rotation_check=rotation_check).eval()
+    if workload == "mesh_fwdbwd":
+        rng = np.random.default_rng(1)
+        azim = (azim + torch.from_numpy(rng.uniform(-5, 5, (B, V)).astype(np.float32)).to(dev)).requires_grad_(True)
+        elev = (elev + torch.from_numpy(rng.uniform(-5, 5, (B, V)).astype(np.float32)).to(dev)).requires_grad_(True)
+        dist_t = (dist_t + torch.from_numpy(rng.uniform(-0.1, 0.1, (B, V)).astype(np.float32)).to(dev)).requires_grad_(True)
+        upstream = torch.randn(B, V, 3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+
+    def render():
+        if workload == "mesh_fwdbwd":
+            azim.grad = elev.grad = dist_t.grad = None
+            img, _ = renderer(packed, None, azim, elev, dist_t)
+            img.backward(upstream)
+            return img
+        with torch.no_grad():
+            return renderer(packed, points, azim, elev, dist_t)[0]
+
+    for _ in range(untimed):
+        out = render()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = render()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # kernel durations: HIP events on the launch stream (library-side), the same number of steps; the mesh pre-pass in a pass of its own
+    kind = 1 if workload == "points_fwd" else 0
+    ms, cnt = (ctypes.c_double * 8)(), (ctypes.c_int32 * 8)()
+    lib.mvr_profile_begin()
+    for _ in range(steps):
+        render()
+    lib.mvr_profile_end(ms, cnt)
+    torch.cuda.synchronize()
+    kern_ms = ms[kind] / max(1, cnt[kind])
+    alg = algorithmic_bytes("mesh_fwd" if workload == "mesh_fwdbwd" else workload, B, V, H, W, nv_list, nf_list, P)
+    res = {"workload": "%s: B=%d x %d views, %dx%d%s" % (workload, B, V, H, W, "" if workload == "points_fwd" else ", geometry %s, tier %s" % (geometry, tier)),
+           "value": B * V * steps / elapsed, "unit": "views/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "untimed_steps": untimed,
+           "kernel": "k_points_raster_shade" if workload == "points_fwd" else "k_mesh_raster_fast", "kernel_ms": kern_ms,
+           "algorithmic_bytes_per_launch": alg, "frac": (alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms > 0 else None}
+    if workload == "mesh_fwdbwd":
+        if cnt[2] > 0:
+            res["backward_kernel_ms"] = ms[2] / cnt[2]
+        alg_step = algorithmic_bytes("mesh_fwdbwd", B, V, H, W, nv_list, nf_list, P)
+        res["step_algorithmic_bytes"] = alg_step
+        res["step_frac"] = alg_step / (elapsed / steps) / 1e9 / HBM_PEAK_GBS
+    if workload.startswith("mesh"):
+        from mvtn_amd import functional as F
+        with torch.no_grad():
+            Rm, Tm = F.look_at_view_transform(dist_t.detach().reshape(-1), elev.detach().reshape(-1), azim.detach().reshape(-1))
+            sp = F.mesh_params(V, H, 1, (0.99999,) * 3, (0.99999,) * 3)
+            st4 = [int(x) for x in F.render_meshes_fragments(packed, Rm, Tm, torch.tensor([[0.0, 1.0, 0.0]], device=dev), sp, return_stats=True)[2].cpu()]
+        n_strips_all = B * V * ((H + 7) // 8)
+        res["fast_raster_stats"] = {"strips": n_strips_all, "strips_redone_by_exact_body": st4[0], "settle_candidates": st4[1],
+                                    "entries_rasterised_by_a_whole_wave": st4[2], "strip_list_entries": st4[3], "prepass_kernel_ms": None}
+        os.environ["MVR_PROF_MASK"] = "0x20"
+        lib.mvr_profile_begin()
+        for _ in range(steps):
+            render()
+        ms5, cnt5 = (ctypes.c_double * 8)(), (ctypes.c_int32 * 8)()
+        lib.mvr_profile_end(ms5, cnt5)
+        del os.environ["MVR_PROF_MASK"]
+        torch.cuda.synchronize()
+        if cnt5[5]:
+            res["fast_raster_stats"]["prepass_kernel_ms"] = ms5[5] / cnt5[5]
+    res["max_pixel_err_vs_oracle"] = None
+    if with_oracle:
+        # bounded: object 0 (ragged: its first tier-M object, index 1), the first 4 views
+        from oracle import oracle as orc
+        ob = 1 if geometry == "ragged" else 0
+        nvw = min(4, V)
+        img = out.detach()[ob:ob + 1, :nvw].cpu().numpy()
+        a_, e_, d_ = (x.detach()[ob:ob + 1, :nvw].cpu().numpy() for x in (azim, elev, dist_t))
+        if workload == "points_fwd":
+            want = orc.render_points(points[ob:ob + 1].cpu().numpy(), a_, e_, d_, H, radius=0.006, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3,
+                                     return_fragments=False)
+        else:
+            vn, fn = vl[ob].numpy(), fl[ob].numpy()
+            ld = orc.camera_position(a_, e_, d_) if workload == "mesh_fwdbwd" else ((0.0, 1.0, 0.0),)
+            # vertices whose face normals cancel (a shell and its reversed copy on shared vertices) are shaded from the noise of a float
+            # sum's order in the reference; only for such meshes the oracle sums as the library does (order-independent): switch #4
+            exact_sum = bool(orc.cancelled_normal_vertices(vn, fn).any())
+            orc.set_normals_exact_sum(exact_sum)
+            want = orc.render_meshes([vn], [fn], a_, e_, d_, H, light_dir=ld, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, return_fragments=False)
+            orc.set_normals_exact_sum(False)
+            res["oracle_normals_exact_sum"] = exact_sum
+        res["max_pixel_err_vs_oracle"] = float(np.abs(img - want["images"]).max())
+        res["parity_sample"] = "object %d, first %d views" % (ob, nvw)
+    del renderer, packed, points, out
+    torch.cuda.empty_cache()
+    return res
 
 
 def self_launch(args):
@@ -504,8 +637,10 @@ def main():
         TH = args.strip_rows or 8
         n_strips_all = B * V * ((H + TH - 1) // TH)
         fast_stats = {"strips": n_strips_all, "strips_redone_by_exact_body": st4[0], "redo_fraction": st4[0] / n_strips_all,
-                      "ambiguous_pixels_settled_in_kernel": st4[1], "strip_list_entries": st4[3], "entries_on_wave_per_face_path": st4[2],
-                      "wide_share": (st4[2] / st4[3]) if st4[3] else None,
+                      "settle_candidates": st4[1],                    # (pixel, face) candidates the exact settle was handed (up to 4 per pixel pair)
+                      "strip_list_entries": st4[3],
+                      "entries_rasterised_by_a_whole_wave": st4[2],   # the "fat" wide faces only; thin wide entries run one lane per row and are not counted
+                      "whole_wave_share": (st4[2] / st4[3]) if st4[3] else None,
                       "prepass_kernel_ms": None}
         os.environ["MVR_PROF_MASK"] = "0x20"   # the pre-pass alone, in a pass of its own
         lib.mvr_profile_begin()
@@ -580,6 +715,22 @@ def main():
             orc.set_normals_exact_sum(False)
             parity = float(np.abs(img - want["images"]).max())
 
+    # ---- `secondary`: the driver's command also measures the workloads the headline does not — the CAD-like and
+    # ragged batches of configs[1], C3 fwd+bwd, C4 points, the per-GPU share of C5 — each from 100 untimed + --secondary-steps timed
+    # steps in this process, after the headline's numbers are final (nothing here changes `value`, `config` or `roofline`)
+    secondary = None
+    if (rank == 0 and world == 1 and not dist_on and wl_name == "mesh_fwd" and args.geometry == "ico" and not args.host_meshes
+            and not args.no_secondary and not args.batch and not args.views and args.image_size == 224 and args.tier == "M" and not args.strip_rows):
+        secondary = {}
+        del out
+        t_sec = time.perf_counter()
+        for nm in SECONDARY:
+            try:
+                secondary[nm] = measure_secondary(nm, dev, lib, H, max(1, args.secondary_steps), 100, not args.no_cpu_baseline, args.rotation_check)
+            except Exception as exc:   # (a failure here must not lose the headline)
+                secondary[nm] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        secondary["seconds"] = time.perf_counter() - t_sec
+
     if rank == 0:
         if fixed_total:
             wl = "C5: 64 tier-L meshes x %d spherical views in total, %dx%d, mesh render fwd%s; %d..%d objects per GPU" % (
@@ -629,6 +780,8 @@ def main():
             line["hip_graph_replay"] = graphed
         if single_thread is not None:
             line["eager_autograd_single_thread"] = single_thread
+        if secondary is not None:
+            line["secondary"] = secondary
         sys.stdout.flush()
         try:
             ctypes.CDLL(None).fflush(None)   # C stdio of the libraries (the RCCL banner is buffered there): out to stderr now

@@ -265,9 +265,13 @@ int mvr_mesh_clip_straddlers(const mvr_mesh_batch *meshes, const mvr_mesh_params
 int mvr_mesh_redo_count(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const void *workspace, size_t workspace_bytes,
                         int32_t *count, mvr_stream_t stream);
 
-/* More of the same, counts: 4 device ints: [0] the redo count above; [1] pixels whose depth order the fast rasteriser could not
- * prove and settled with the reference's exact test inside its own workgroup (per strip capped at 255); [2] strip-list entries
- * (a face is listed once per strip it reaches) wider than 16 pixels, rasterised by a whole wave; [3] strip-list entries in all. */
+/* More of the same, counts: 4 device ints: [0] the redo count above; [1] the (pixel, face) CANDIDATES the fast rasteriser recorded
+ * where it could not prove the depth order and handed to the reference's exact test inside its own workgroup (up to 4 per pixel
+ * pair and meeting; per strip capped at 32 767) — not a pixel count; [2] strip-list entries (a face is listed once per strip it
+ * reaches) that a WHOLE WAVE rasterised: the "fat" ones among the entries wider than 16 pixels (a wide entry none of whose rows
+ * is longer than 8 pixel pairs runs one lane per row and is not counted); per strip capped at 16 383; [3] strip-list entries in
+ * all.  A strip the exact body redid contributes to [1] / [2] what the fast path had counted before it gave up (0 when it never
+ * started). */
 int mvr_mesh_fast_stats(const mvr_mesh_batch *meshes, const mvr_mesh_params *params, const void *workspace, size_t workspace_bytes,
                         int32_t *counts, mvr_stream_t stream);
 

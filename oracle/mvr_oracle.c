@@ -42,6 +42,13 @@ void orc_set_edge_fma(int on) { orc_edge_fma = on ? 1 : 0; }
  *       64-bit fixed-point sums (see orc_vertex_normals).  Differs visibly only at vertices whose face normals cancel. */
 static int orc_normals_exact_sum = 0;
 void orc_set_normals_exact_sum(int on) { orc_normals_exact_sum = on ? 1 : 0; }
+/*   projection_bmm (round 6): 0 (default) = world -> view as the closed form ((x r0 + y r1) + z r2) + t, every
+ *       product and sum rounded — what the library computes; 1 = the same sum as a K = 4 GPU matrix product accumulates it
+ *       (ascending k, fused multiply-adds): PyTorch3D projects vertices through Transform3d.transform_points = torch.bmm.  Which
+ *       of two COINCIDENT faces (a shell and its reversed copy) has the smaller interpolated depth is decided in the last bit of
+ *       pz, i.e. by the rounding sequence of the projection: this switch measures how many pixels that moves. */
+static int orc_projection_bmm = 0;
+void orc_set_projection_bmm(int on) { orc_projection_bmm = on ? 1 : 0; }
 /* soft path, round 4: which PIECE of a cut face every fragment of the K-nearest lists lies on (clip_face's index; -1: the face
  * is whole) — written by the next orc_render_meshes_soft_* call when `out` is set ((N,H,W,K) int32), and, with a fixed list,
  * read from `fixed` so that the listed fragments are evaluated on the same pieces again (finite differences of the clipped

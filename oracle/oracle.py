@@ -66,6 +66,14 @@ def set_normals_exact_sum(on=False):
     lib().orc_set_normals_exact_sum(ctypes.c_int(int(bool(on))))
 
 
+def set_projection_bmm(on=False):
+    """Switch #5 (round 6): True = the world -> view transform accumulated like a K = 4 GPU matrix product (ascending k, fused
+    multiply-adds: PyTorch3D's transform_points is a torch.bmm); False = the closed form with every operation rounded (default,
+    what the library computes).  Moves only which of two COINCIDENT faces wins a pixel (orc_set_projection_bmm in mvr_oracle.c).
+    Process-wide."""
+    lib().orc_set_projection_bmm(ctypes.c_int(int(bool(on))))
+
+
 def cancelled_normal_vertices(verts, faces, rel=1e-4):
     """Boolean (Vn,) mask of the vertices whose area-weighted face normals cancel: |sum_f n_f| < rel * sum_f |n_f| (float64)."""
     v = np.asarray(verts, np.float64)

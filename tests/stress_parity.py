@@ -44,7 +44,11 @@ for case in range(n_cases):
     zc = 0.5 if (persp and rng.integers(0, 2)) else 0.0   # PyTorch3D >= 0.5's face clipping (cuts faces when dist < ~1.5)
     if case < first_case:
         continue
-    oracle.set_normals_exact_sum(True)   # (the library's sums: coincident shells on shared vertices have normals that cancel — a float sum there is noise of its order)
+    # The oracle's default vertex-normal sums are the reference's form (a float index_add in face order).  Only where a mesh has
+    # vertices whose face normals CANCEL (a shell and its reversed copy on shared vertices: a float sum there is noise of its
+    # order, the library's order-independent sums give exactly 0) the oracle sums as the library does (switch #4) — ADVICE r5.
+    exact_sum = any(bool(oracle.cancelled_normal_vertices(v_, f_).any()) for v_, f_ in zip(vl, fl))
+    oracle.set_normals_exact_sum(exact_sum)
     want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, perspective_correct=persp, cull_backfaces=cull, mode=1,
                                 z_clip=zc)
     packed = PackedMeshes.from_meshes(Meshes(vl, fl), dev)

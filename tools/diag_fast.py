@@ -17,7 +17,8 @@ TIER = os.environ.get("MVR_TIER", "M")     # MVR_TIER=L: the C5 shard (8 tier-L 
 if TIER == "L":
     B, V = 8, 20
 GEO = os.environ.get("MVR_GEOMETRY", "ico")   # ico / cad / ragged (bench.py --geometry)
-vl, fl = zip(*[syn.geometry_mesh(GEO, TIER, i) for i in range(B)])
+SEED0 = int(os.environ.get("MVR_SEED0", "0"))
+vl, fl = zip(*[syn.geometry_mesh(GEO, TIER, SEED0 + i) for i in range(B)])
 packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl]), dev)
 az, el, di = syn.spherical_views(V)
 ta, te, td = (torch.from_numpy(np.tile(x, (B, 1))).to(dev) for x in (az, el, di))
@@ -41,6 +42,25 @@ print("workgroups with work: %d   cycles/workgroup mean %.0f max %.0f; listed fa
     len(d), tot.mean(), tot.max(), d[:, 6].mean(), d[:, 7].sum()))
 print("cycles/workgroup percentiles 50 / 90 / 99 / max: %.0f / %.0f / %.0f / %.0f; sum of workgroup cycles %.3g (a CU holds 4: / 1024 / 2.1e9 = %.1f us if perfectly packed)" % (
     np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), tot.sum(), tot.sum() / 1024 / 2.1e9 * 1e6))
+# per XCD (blockIdx & 7: an XCD owns a contiguous range of views) and per object: is the launch balanced across the chip?
+allr = buf.cpu().numpy().reshape(-1, 8)[:nblocks]
+tot_all = np.where(allr[:, 5] > 0, allr[:, 5] - allr[:, 0], 0).astype(np.float64)
+xs = np.array([tot_all[x::8].sum() for x in range(8)])
+print("summed workgroup cycles per XCD (M): %s   max / mean %.3f" % (" ".join("%.1f" % (x / 1e6) for x in xs), xs.max() / xs.mean()))
+# per object (the launch maps bid -> xcd = bid & 7, j = bid >> 3, view = xcd * vpx + j % vpx)
+vpx = (B * V + 7) // 8
+bid = np.arange(nblocks)
+view_of = (bid & 7) * vpx + (bid >> 3) % vpx
+obj = np.array([tot_all[(view_of // V) == b].sum() for b in range(B)])
+print("summed workgroup cycles per object (M): %s" % " ".join("%.1f" % (x / 1e6) for x in obj))
+srt = np.sort(obj)[::-1]
+bins8 = np.zeros(8)
+for x in srt:
+    bins8[np.argmin(bins8)] += x
+print("  objects dealt to 8 XCDs heaviest-first onto the lightest XCD: max / mean %.3f (as launched: %.3f)" % (bins8.max() / bins8.mean(), xs.max() / xs.mean()))
+t_first, t_last = allr[allr[:, 5] > 0, 0].min(), allr[:, 5].max()
+ends = np.array([allr[x::8, 5].max() - t_first for x in range(8)])
+print("kernel span by the stamps: %.0f cycles; last workgroup of each XCD ends at (k cycles): %s" % (t_last - t_first, " ".join("%.0f" % (e / 1e3) for e in ends)))
 two = d[:, 2] > 0
 names = ["init (tables, key clear, first entries)", "raster (all segments, wave 0)", "wait for the other waves", "exact settle of the candidates + resolve + shade"]
 spans = [d[:, 1] - d[:, 0], d[:, 3] - d[:, 1], d[:, 4] - d[:, 3], d[:, 5] - d[:, 4]]
@@ -67,6 +87,11 @@ X = np.stack([np.ones_like(tot), d[:, 6], n_wide - n_fat, n_fat, d[:, 7]], 1)
 coef, *_ = np.linalg.lstsq(X, tot, rcond=None)
 print("cycles ~ %.0f + %.1f per listed face + %.1f per thin wide entry + %.1f per whole-wave entry + %.2f per candidate" % tuple(coef))
 print("shares of the summed cycles: base %.1f %%, listed %.1f %%, thin wide %.1f %%, whole-wave %.1f %%, candidates %.1f %%" % tuple(100 * coef * X.sum(0) / tot.sum()))
+# round 6: the candidates live in the gap of the strip's list region (two per 16-byte entry): entries a strip needs = listed + candidates / 2
+need = d[:, 6] + np.ceil(d[:, 7] / 2)
+srt = np.sort(need)[::-1]
+print("list-region demand (listed faces + candidates / 2) per strip: max %d, next %s; strips over 2560 / 2752 / 3008: %d / %d / %d" % (
+    srt[0], " ".join("%d" % x for x in srt[1:8]), (need > 2560).sum(), (need > 2752).sum(), (need > 3008).sum()))
 order = np.argsort(-tot)[:12]
 print("heaviest strips: cycles | listed, thin wide, whole-wave, candidates | init, raster(w0), wait, settle+resolve")
 for i in order:
