@@ -55,6 +55,13 @@ enum {
                                   (v0-v2)x(v1-v2) to vertex 2, (v1-v0)x(v2-v0) to vertex 0 — instead of one added to all
                                   three: the two forms PyTorch3D's Meshes._compute_vertex_normals has had; equal in exact
                                   arithmetic, ~1e-7 apart in fp32 (colours only; never coverage).  Pass it to forward AND backward */
+  MVR_PROJECTION_FMA = 128,    /* world -> view as a batched matrix product accumulates it on a GPU (ascending k, fused
+                                  multiply-adds: PyTorch3D's Transform3d.transform_points is a torch.bmm) instead of the closed
+                                  form with every product and sum rounded (default).  The two differ in the last bit of a view
+                                  coordinate: which of two COINCIDENT faces (a shell and its reversed copy — the reference ships
+                                  lists of such ModelNet meshes, custom_dataset.py:92-98) wins a pixel follows; nothing else
+                                  moves.  With it and fov_scale = torch's K[0][0] the pixel -> face map equals a torch-op
+                                  restatement of the reference's pipeline on such a mesh at every pixel */
   MVR_KEEP_PIXEL_LISTS = 32    /* forward with pix_to_face: also leave, per (view, strip), the list of covered pixels with
                                   their winners' slots and the winners' faces in the workspace (the rasteriser has them at
                                   hand); a backward given the same workspace with MVR_WORKSPACE_FROM_FORWARD and this flag

@@ -18,6 +18,7 @@ MVR_RASTER_EXACT_ONLY = 8
 MVR_BACKWARD_GATHER = 16
 MVR_KEEP_PIXEL_LISTS = 32
 MVR_NORMALS_THREE_CROSS = 64
+MVR_PROJECTION_FMA = 128
 MVR_SHADER_SOFT_PHONG, MVR_SHADER_SOFT_SILHOUETTE = 0, 1
 
 

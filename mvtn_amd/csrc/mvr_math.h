@@ -348,9 +348,23 @@ template <typename T> MVR_HD V3<T> world_to_view(const T R[9], const T Tr[3], co
 MVR_HD float fov_scale(float fov_deg) { return (float)(1.0 / tan(((double)fov_deg * (kPi / 180.0)) / 2.0)); }
 MVR_HD double fov_scale(double fov_deg) { return 1.0 / tan((fov_deg * (kPi / 180.0)) / 2.0); }
 
-// NDC x, y and VIEW z of a world vertex (MeshRasterizer.transform).
-template <typename T> MVR_HD V3<T> project_vertex(const T R[9], const T Tr[3], T s, const V3<T> &X) {
-  V3<T> v = world_to_view(R, Tr, X);
+// MVR_PROJECTION_FMA (round 6): the same sum the way a batched 4 x 4 matrix product accumulates it on a GPU — ascending k, every
+// product after the first fused into the running sum; PyTorch3D projects vertices through Transform3d.transform_points =
+// torch.bmm([X 1], [[R, 0], [T, 1]]) (the k = 3 term is 1 * T: fma(1, T, acc) = acc + T; the homogeneous coordinate is exactly 1).
+// The two forms differ in the last bit of a view coordinate; that decides which of two COINCIDENT faces (a shell and its reversed
+// copy) has the smaller interpolated depth, nothing else (oracle switch #5, tests/test_oracle.py).
+MVR_HD float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+MVR_HD double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename T> MVR_HD V3<T> world_to_view_fma(const T R[9], const T Tr[3], const V3<T> &X) {
+  return {fma_t(X.z, R[6], fma_t(X.y, R[3], X.x * R[0])) + Tr[0],
+          fma_t(X.z, R[7], fma_t(X.y, R[4], X.x * R[1])) + Tr[1],
+          fma_t(X.z, R[8], fma_t(X.y, R[5], X.x * R[2])) + Tr[2]};
+}
+
+// NDC x, y and VIEW z of a world vertex (MeshRasterizer.transform).  ([x y z 1] K has one nonzero product per component — x s,
+// y s, z —, so a fused chain rounds it as this closed form does.)
+template <typename T> MVR_HD V3<T> project_vertex(const T R[9], const T Tr[3], T s, const V3<T> &X, bool fma_sum = false) {
+  V3<T> v = fma_sum ? world_to_view_fma(R, Tr, X) : world_to_view(R, Tr, X);
   return {(s * v.x) / v.z, (s * v.y) / v.z, v.z};
 }
 

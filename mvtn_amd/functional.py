@@ -126,7 +126,7 @@ def camera_position_from_spherical_angles(distance, elevation, azimuth):
 
 def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backfaces=False, perspective_correct=True,
                 fov=60.0, ambient=0.5, diffuse=0.3, specular=0.2, shininess=64.0, strip_rows=0, exact_raster=False, z_clip=None,
-                gather_backward=False, normalize=None, fov_scale=0.0, normals_three_cross=True):
+                gather_backward=False, normalize=None, fov_scale=0.0, normals_three_cross=True, projection_fma=False):
     """`exact_raster`: skip the fast rasteriser (MVR_RASTER_EXACT_ONLY); the images are the same either way.
     `gather_backward`: skip the face-table backward kernel (MVR_BACKWARD_GATHER); same gradients up to summation order.
     `normalize`: (mean, std) per channel (or scalars): the trainer's Normalize, (rgb - mean) / std, applied in the
@@ -136,7 +136,9 @@ def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backface
     `fov_scale`: 0 = the projection scale from `fov` (1 / tan(fov / 2) evaluated in double, rounded once); > 0: used as given
     (K[0][0] of a particular PyTorch3D build).  `normals_three_cross` (default): the vertex normals from three cross products per
     face (MVR_NORMALS_THREE_CROSS: Meshes._compute_vertex_normals of the PyTorch3D releases of the reference's era); False: one
-    cross product per face added to its three vertices (the later form).  ~1e-7 apart, colours only."""
+    cross product per face added to its three vertices (the later form).  ~1e-7 apart, colours only.  `projection_fma`:
+    MVR_PROJECTION_FMA — world -> view accumulated like a GPU matrix product (PyTorch3D's transform_points is a torch.bmm) instead of
+    the closed form; decides only which of two coincident faces wins a pixel."""
     if z_clip is None:
         z_clip = 0.5 if perspective_correct else 0.0
     H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
@@ -144,6 +146,7 @@ def mesh_params(n_views, image_size, n_light, obj_color, bg_color, cull_backface
     flags |= _lib.MVR_RASTER_EXACT_ONLY if exact_raster else 0
     flags |= _lib.MVR_BACKWARD_GATHER if gather_backward else 0
     flags |= _lib.MVR_NORMALS_THREE_CROSS if normals_three_cross else 0
+    flags |= _lib.MVR_PROJECTION_FMA if projection_fma else 0
     p = _lib.MeshParams(n_views, H, W, flags, n_light, strip_rows, fov, ambient, diffuse, specular, shininess)
     for k in range(3):
         p.obj_color[k] = float(obj_color[k])

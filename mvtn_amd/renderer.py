@@ -59,12 +59,15 @@ class MVRenderer(nn.Module):
                  faces_per_pixel=1, points_radius=0.006, points_per_pixel=1, light_direction="random",
                  cull_backfaces=False, *, perspective_correct=True, rotation_check="device", strip_rows=0, z_clip=None,
                  shader="hard_phong", blur_radius=0.0, sigma=1e-4, gamma=1e-4, return_alpha=False, normalize=None,
-                 fov_scale=0.0, normals_three_cross=True):
+                 fov_scale=0.0, normals_three_cross=True, projection_fma=False):
         super().__init__()
         # the two places where a PyTorch3D build may differ from the defaults in the last bit (functional.mesh_params):
         # fov_scale > 0 = that build's K[0][0]; normals_three_cross (default) = vertex normals from three cross products per face,
         # PyTorch3D's form in the reference's era; False = one cross product per face (the later form)
         self.fov_scale, self.normals_three_cross = float(fov_scale), bool(normals_three_cross)
+        # projection_fma: world -> view accumulated like a GPU matrix product (PyTorch3D's transform_points is a torch.bmm) instead of
+        # the closed form: moves only which of two COINCIDENT faces wins a pixel (functional.mesh_params; oracle switch #5)
+        self.projection_fma = bool(projection_fma)
         # normalize=(mean, std): the trainer's Normalize (viewGCN/tools/Trainer_mvt.py:41-49) applied in the mesh rasteriser's
         # stores — the images come out as (rgb - mean) / std, differentiably, with no pass over the frames afterwards
         # (mvtn_amd.regularize.IMAGENET_MEAN / IMAGENET_STD are the reference's values).  Hard mesh path and point path.
@@ -233,7 +236,7 @@ class MVRenderer(nn.Module):
         pkey = (n_light, obj if isinstance(obj, tuple) else tuple(obj),
                 background_color if isinstance(background_color, tuple) else tuple(float(c) for c in background_color),
                 self.cull_backfaces, self.perspective_correct, self.strip_rows, self.nb_views, self.image_size, self.z_clip,
-                self.normalize, self.fov_scale, self.normals_three_cross, self.shader)
+                self.normalize, self.fov_scale, self.normals_three_cross, self.shader, self.projection_fma)
         params = self._params_cache.get(pkey)
         if params is None:
             if len(self._params_cache) > 64:
@@ -243,7 +246,8 @@ class MVRenderer(nn.Module):
                                                               cull_backfaces=bool(pkey[3]), perspective_correct=bool(pkey[4]),
                                                               strip_rows=self.strip_rows, z_clip=self.z_clip,
                                                               normalize=self.normalize if self.shader == "hard_phong" else None,
-                                                              fov_scale=self.fov_scale, normals_three_cross=self.normals_three_cross)
+                                                              fov_scale=self.fov_scale, normals_three_cross=self.normals_three_cross,
+                                                              projection_fma=self.projection_fma)
         if azim.numel() != N:
             raise ValueError("azim/elev/dist must be (B, nb_views) = (%d, %d)" % (packed.n_meshes, self.nb_views))
         if window is not None:   # render straight onto the view regulariser's window (regularize.draw_regularization)

@@ -1,0 +1,854 @@
+"""-m gpu: the hard mesh forward (pre-pass, fast + exact rasterisers, Phong + hard blend) through the C ABI against the CPU oracle and the torch restatements: pixel -> face maps bit-exact, images <= 1e-4.
+
+Filed by component in round 6; where each test came from (stable test names, so that rounds stay comparable):
+  test_vertex_normals                                                         test_gpu_parity.py
+  test_mesh_forward_parity                                                    test_gpu_parity.py
+  test_mesh_custom_vertex_colors                                              test_gpu_parity.py
+  test_refined_reciprocal_is_correctly_rounded_exhaustive                     test_gpu_parity.py
+  test_full_size_properties                                                   test_gpu_parity.py
+  test_edge_case_flat_band_many_faces_per_strip                               test_gpu_parity.py
+  test_edge_case_huge_and_tiny_faces                                          test_gpu_parity.py
+  test_edge_case_strip_list_overflow_falls_back_to_the_scan                   test_gpu_parity.py
+  test_edge_case_mesh_too_large_for_the_fused_prepass                         test_gpu_parity.py
+  test_edge_case_nothing_visible_and_large_image                              test_gpu_parity.py
+  test_known_answers_mesh_hip                                                 test_gpu_parity.py
+  test_random_configurations_slice                                            test_gpu_parity.py
+  test_fast_rasteriser_equals_exact_kernel                                    test_gpu_parity.py
+  test_full_size_c2_all_meshes_against_the_oracle                             test_gpu_parity.py
+  test_prepass_lists_of_very_large_face_counts                                test_gpu_parity.py
+  test_custom_vertex_colours_with_a_packed_batch                              test_gpu_parity.py
+  test_z_clip_cuts_faces_like_the_reference                                   test_gpu_parity.py
+  test_hip_path_against_the_torch_restatement_of_c1                           test_gpu_parity.py
+  test_hip_face_clipping_against_the_torch_restatement                        test_gpu_round3.py
+  test_library_switches_follow_the_oracle_switches                            test_gpu_round3.py
+  test_fast_rasteriser_lds_layouts_against_the_exact_kernel                   test_gpu_round3.py
+  test_fast_rasteriser_faces_with_tiny_edge_coefficients                      test_gpu_round4.py
+  test_cad_meshes_pix_to_face_bit_exact                                       test_gpu_round5.py
+  test_ragged_batch_pix_to_face_bit_exact                                     test_gpu_round5.py
+  test_hip_against_torch_restatement_on_cad_and_ragged_meshes                 test_gpu_round5.py
+  test_untrusted_face_over_the_left_image_border                              test_gpu_round5.py
+  test_stacks_of_coincident_faces_fill_the_candidate_area                     test_gpu_round5.py
+  test_scheduling_hints_never_change_a_pixel                                  test_gpu_round5.py
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mvtn_amd import synthetic as syn
+
+from gpu_helpers import _dev, _fx, _hip_render_mesh, _mesh_batch, _oracle_both_normal_sums, _render, _render_pair, _t, _tris, _views, _well_conditioned_pixels, TOL_PIXEL  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+_TUNING_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+from mvtn_amd import MVRenderer, Meshes, synthetic as syn
+dev = torch.device("cuda:0")
+out = {}
+v, f = syn.synthetic_mesh("M", 0)
+pts = torch.from_numpy(syn.surface_points(v, f, 2048, 0)[None])
+for S in (128, 224, 448):
+    az, el, di = (torch.from_numpy(x[None].copy()).to(dev) for x in syn.spherical_views(12))
+    with torch.no_grad():
+        img, _ = MVRenderer(12, S, pc_rendering=False, light_direction="fixed").eval()([Meshes([v], [f])], None, az, el, di)
+        # (>= 4096 workgroups: what the point rasteriser's start stagger needs to be active at all)
+        azp, elp, dip = (torch.from_numpy(np.tile(x, (15, 1))).to(dev) for x in syn.spherical_views(20))
+        imgp, _ = MVRenderer(20, S, pc_rendering=True, points_radius=0.006).eval()(None, pts.expand(15, -1, -1).contiguous(), azp, elp, torch.ones_like(dip))
+    out["mesh_%d" % S] = img.cpu().numpy()
+    out["points_%d" % S] = imgp.cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_vertex_normals(oracle):
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = _mesh_batch([("S", 0), ("M", 1), ("soup", 2)])
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    got = F.vertex_normals(packed).cpu().numpy()
+    got2 = F.vertex_normals(packed).cpu().numpy()
+    assert np.array_equal(got, got2), "fixed-point accumulation must be bit-reproducible"
+    want = np.concatenate([oracle.vertex_normals(v, f) for v, f in zip(vl, fl)], 0)
+    # summation order differs from the sequential index_add (exact fixed-point sum vs float adds);
+    # the CAD soup's normals cancel to rounding noise and are excluded (see _well_conditioned_pixels)
+    n_ok = len(vl[0]) + len(vl[1])
+    assert np.abs(got[:n_ok] - want[:n_ok]).max() < 2e-5
+    assert np.isfinite(got).all() and np.abs(np.linalg.norm(got[:n_ok], axis=1) - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("size,specs,V,persp,cull,light,strip", [
+    (128, [("M", 0)], 4, True, False, "fixed", 0),                                  # C1
+    (224, [("M", 0), ("M", 1)], 12, True, False, "fixed", 0),                       # C2 slice
+    (224, [("L", 2), ("L", 3)], 20, True, False, "fixed", 0),                       # C5 slice: ShapeNet-sized meshes, 20 views
+    (224, [("S", 3), ("L", 4), ("soup", 5), ("M", 6)], 6, True, False, "relative", 0),  # ragged + CAD soup
+    (224, [("M", 7), ("soup", 8)], 4, False, True, "fixed", 0),                     # 0.4-style switches
+    (96, [("S", 9)], 3, True, False, "fixed", 5),                                   # odd strip height
+    (37, [("S", 10), ("soup", 11)], 2, True, True, "relative", 0),                  # odd image size
+])
+def test_mesh_forward_parity(oracle, size, specs, V, persp, cull, light, strip):
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = _mesh_batch(specs)
+    B = len(vl)
+    az, el, di = _views(B, V, seed=len(specs) + V) if V in (4, 6, 12, 20) else _views(B, 4, 1)
+    az, el, di = az[:, :V], el[:, :V], di[:, :V]
+    if size == 128:  # C1: the reference's own circular configuration
+        a, e, d = syn.circular_views(4, 30.0, 2.2)
+        az, el, di = a[None], e[None], d[None]
+    obj, bg = (0.99999, 0.99999, 0.99999), (0.99999, 0.99999, 0.99999)
+    ldir = oracle.camera_position(az, el, di) if light == "relative" else np.array([[0.0, 1.0, 0.0]], np.float32)
+    want = oracle.render_meshes(vl, fl, az, el, di, size, light_dir=ldir, obj_color=obj, bg_color=bg,
+                                perspective_correct=persp, cull_backfaces=cull, mode=1)
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    params = F.mesh_params(V, size, ldir.shape[0], obj, bg, cull_backfaces=cull, perspective_correct=persp, strip_rows=strip)
+    img, p2f = F.render_meshes_fragments(packed, R, T, _t(ldir), params)
+    torch.cuda.synchronize()
+    p2f, img = p2f.cpu().numpy(), img.cpu().numpy()
+    n_diff = int((p2f != want["pix_to_face"]).sum())
+    well = _well_conditioned_pixels(vl, fl, want["pix_to_face"], V)
+    diff = np.abs(img - want["images"]).reshape(B * V, 3, size, size).max(1)
+    err = float(diff[well].max())
+    print("coverage mismatches: %d  max|d|: %.3g  covered: %.3f  ill-conditioned px: %d" % (
+        n_diff, err, (p2f >= 0).mean(), int((~well).sum())))
+    assert n_diff == 0, "pixel->face map differs from the oracle at %d pixels" % n_diff
+    assert err <= TOL_PIXEL
+    assert img.shape == (B, V, 3, size, size) and np.isfinite(img).all()
+
+
+def test_mesh_custom_vertex_colors(oracle):
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = _mesh_batch([("S", 0), ("M", 1)])
+    rng = np.random.default_rng(0)
+    mx = max(len(v) for v in vl)
+    col = rng.uniform(0, 1, (2, mx, 3)).astype(np.float32)
+    vc = np.concatenate([col[b, :len(v)] for b, v in enumerate(vl)], 0)
+    az, el, di = _views(2, 4, 3)
+    want = oracle.render_meshes(vl, fl, az, el, di, 64, vert_colors=vc, bg_color=(0, 0, 0))
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev(), vert_colors=torch.from_numpy(col))
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    params = F.mesh_params(4, 64, 1, (1, 1, 1), (0, 0, 0))
+    img, p2f = F.render_meshes_fragments(packed, R, T, _t([[0, 1, 0]]), params)
+    assert np.array_equal(p2f.cpu().numpy(), want["pix_to_face"])
+    assert np.abs(img.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+
+
+def test_refined_reciprocal_is_correctly_rounded_exhaustive():
+    """The rasteriser's perspective-correct barycentrics divide by den through y = RN(1/den) (Markstein); y comes
+    from v_rcp_f32 + two Newton steps.  Check y == 1.0f / den (IEEE) for EVERY float in [2^-30, 2^24): all 2^23
+    mantissas of 54 binades — den = max(., 1e-8) is >= 2^-27 and a sum of three z_i z_j-scaled barycentrics."""
+    from mvtn_amd import _lib
+    lib = _lib.load()
+    out = torch.zeros(2, dtype=torch.int32, device=_dev())
+    lo = np.array([2.0 ** -30], np.float32).view(np.uint32)[0]
+    hi = np.array([2.0 ** 24], np.float32).view(np.uint32)[0] - 1
+    _lib.check(lib.mvr_selftest_rcp(int(lo), int(hi), out[0:1].data_ptr(), out[1:2].data_ptr(), None), "mvr_selftest_rcp")
+    torch.cuda.synchronize()
+    n_bad, first = int(out[0]), int(out[1]) & 0xFFFFFFFF
+    assert n_bad == 0, "%d mismatches, e.g. bits 0x%08x" % (n_bad, first)
+
+
+def test_full_size_properties():
+    """BASELINE config C2 at full size (B=16, V=12, 224^2): size-independent properties —
+    determinism, background constant, silhouette fraction of a unit sphere (KA2), views of the
+    same mesh from mirrored azimuths are mirror images in coverage count."""
+    from mvtn_amd import MVRenderer, Meshes
+    B, V = 16, 12
+    meshes = [Meshes([v], [f]) for v, f in (syn.synthetic_mesh("M", s) for s in range(B))]
+    az, el, di = syn.spherical_views(V)
+    ta, te, td = (_t(np.tile(x, (B, 1))) for x in (az, el, di))
+    r = MVRenderer(V, 224, pc_rendering=False, light_direction="fixed", rotation_check="off").eval()
+    a, _ = r(meshes, None, ta, te, td)
+    b, _ = r(meshes, None, ta, te, td)
+    assert a.shape == (B, V, 3, 224, 224)
+    assert torch.equal(a, b), "render is not deterministic"
+    bg = np.float32(1.0) / np.float32(1.00001)
+    assert float(a.max()) <= 1.0 + 1e-6 and float(a.min()) >= 0.49
+    assert (a == float(bg)).float().mean() > 0.3  # background pixels are exactly 0.99999 (KA6)
+    # KA2: unit sphere at d = 2.2, fov 60: silhouette radius 0.88388 NDC -> 61.36 % of the image
+    vs, fs = syn.icosphere(5)
+    sph = [Meshes([torch.from_numpy(vs.astype(np.float32))], [torch.from_numpy(fs)])]
+    r1 = MVRenderer(1, 224, pc_rendering=False, light_direction="fixed", background_color="black", rotation_check="off").eval()
+    img, _ = r1(sph, None, _t([[30.0]]), _t([[20.0]]), _t([[2.2]]))
+    frac = float((img[0, 0].sum(0) > 0).float().mean())
+    assert abs(frac - 0.6136) < 0.004, frac
+
+
+def test_edge_case_flat_band_many_faces_per_strip(oracle):
+    """20 480 faces squeezed into a few image rows: > 8192 faces (several scan passes) and far more than
+    MVR_LIST_CAP faces touching one strip (list windows), thousands of coincident-depth candidates per pixel."""
+    v, f = syn.synthetic_mesh("L", 3)
+    v = v.copy()
+    v[:, 1] *= 0.03
+    az, el, di = np.array([[20.0, 200.0]], np.float32), np.array([[0.0, 3.0]], np.float32), np.full((1, 2), 2.2, np.float32)
+    img, p2f, want = _render_pair(oracle, [v], [f], az, el, di, 224)
+    assert int((p2f != want["pix_to_face"]).sum()) == 0
+    assert (p2f >= 0).sum() > 1000
+    well = _well_conditioned_pixels([v], [f], want["pix_to_face"], 2)
+    assert np.abs(img - want["images"]).reshape(2, 3, 224, 224).max(1)[well].max() <= TOL_PIXEL
+
+
+def test_edge_case_huge_and_tiny_faces(oracle):
+    """Two triangles covering the whole frame (every strip, every lane of the balanced loop shares one face), a
+    sub-pixel sliver, a degenerate (zero-area) face and a face behind the camera."""
+    big = [[-4, -4, 0.1], [4, -4, 0.1], [0, 4, 0.1], [-4, 4, -0.2], [4, 4, -0.2], [0, -4, -0.2]]
+    sliver = [[0.0, 0.0, 0.5], [0.004, 0.0, 0.5], [0.0, 0.004, 0.5]]
+    degenerate = [[0.1, 0.1, 0.6], [0.2, 0.2, 0.6], [0.3, 0.3, 0.6]]
+    behind = [[-1, -1, 5.0], [1, -1, 5.0], [0, 1, 5.0]]
+    v = np.asarray(big + sliver + degenerate + behind, np.float32)
+    f = np.arange(len(v)).reshape(-1, 3).astype(np.int64)
+    az, el, di = np.array([[0.0, 10.0, 180.0]], np.float32), np.array([[0.0, 5.0, 0.0]], np.float32), np.full((1, 3), 2.2, np.float32)
+    for size, strip in ((64, 0), (224, 0), (50, 3)):
+        img, p2f, want = _render_pair(oracle, [v], [f], az, el, di, size, strip=strip)
+        assert int((p2f != want["pix_to_face"]).sum()) == 0, (size, strip)
+        assert np.abs(img - want["images"]).max() <= TOL_PIXEL
+        assert (p2f[0] >= 0).mean() > 0.9
+
+
+def test_edge_case_strip_list_overflow_falls_back_to_the_scan(oracle):
+    """400 large overlapping triangles: every face reaches most strips, the per-strip lists of the pre-pass exceed their
+    reserved capacity (3 entries per face + slack), the view is flagged on the device and the rasteriser scans the
+    2-byte bins instead — in several windows of its 256-entry LDS list; the near/far split and the hierarchical-z
+    rejection are off on that path.  A second mesh in the batch keeps its lists: both paths in one launch."""
+    rng = np.random.default_rng(11)
+    n = 400
+    c = rng.uniform(-0.3, 0.3, (n, 1, 3))
+    tri = c + rng.uniform(-0.9, 0.9, (n, 3, 3)) * np.array([1.0, 1.0, 0.15])
+    v_big = tri.reshape(-1, 3).astype(np.float32)
+    f_big = np.arange(3 * n).reshape(-1, 3).astype(np.int64)
+    v_small, f_small = syn.synthetic_mesh("S", 3)
+    az = np.array([[0.0, 77.0], [30.0, 200.0]], np.float32)
+    el = np.array([[0.0, 25.0], [-20.0, 40.0]], np.float32)
+    di = np.full((2, 2), 2.2, np.float32)
+    for size in (224, 96):
+        img, p2f, want = _render_pair(oracle, [v_big, v_small], [f_big, f_small], az, el, di, size)
+        assert int((p2f != want["pix_to_face"]).sum()) == 0, size
+        ok = _well_conditioned_pixels([v_big, v_small], [f_big, f_small], want["pix_to_face"], 2)
+        err = np.abs(img - want["images"]).reshape(4, 3, size, size).max(1)
+        assert err[ok].max() <= TOL_PIXEL
+        assert (p2f[:2] >= 0).mean() > 0.5      # the triangle soup covers most of its views
+
+
+def test_edge_case_mesh_too_large_for_the_fused_prepass(oracle):
+    """40 962 vertices / 81 920 faces: the projected vertices no longer fit in LDS (limit 12 288), so the forward takes
+    the separate launches (chunked vertex normals, k_project_verts, k_face_bins, no strip lists) and the rasteriser scans
+    the bins in several passes of 8192 faces; batched with a small mesh (ragged batch, max_verts decides the path)."""
+    v_big, f_big = syn.synthetic_mesh(6, 5)
+    v_small, f_small = syn.synthetic_mesh("S", 1)
+    assert len(v_big) > 12288
+    az = np.array([[15.0, 250.0], [100.0, -60.0]], np.float32)
+    el = np.array([[20.0, -35.0], [5.0, 50.0]], np.float32)
+    di = np.full((2, 2), 2.2, np.float32)
+    img, p2f, want = _render_pair(oracle, [v_big, v_small], [f_big, f_small], az, el, di, 96)
+    assert int((p2f != want["pix_to_face"]).sum()) == 0
+    assert np.abs(img - want["images"]).max() <= TOL_PIXEL
+    assert (p2f >= 0).mean() > 0.3
+
+
+def test_edge_case_nothing_visible_and_large_image(oracle):
+    """Object behind / beside the camera -> pure background; a 300^2 image (more than 254 rows: row-bins of 2 strips)."""
+    v, f = syn.synthetic_mesh("S", 0)
+    far = v + np.array([0.0, 0.0, 50.0], np.float32)
+    az, el, di = np.array([[0.0]], np.float32), np.array([[0.0]], np.float32), np.array([[2.2]], np.float32)
+    img, p2f, want = _render_pair(oracle, [far], [f], az, el, di, 96)
+    assert (p2f == -1).all() and np.array_equal(p2f, want["pix_to_face"])
+    assert np.allclose(img[0, 0, 0], 0.1) and np.allclose(img[0, 0, 2], 0.3)
+    img, p2f, want = _render_pair(oracle, [v], [f], az, el, di, 300, persp=False)
+    assert int((p2f != want["pix_to_face"]).sum()) == 0 and np.abs(img - want["images"]).max() <= TOL_PIXEL
+    img, p2f, want = _render_pair(oracle, [v], [f], az, el, di, 2200 // 4, strip=2)   # 550 rows / 2 = 275 strips > 254 bins
+    assert int((p2f != want["pix_to_face"]).sum()) == 0
+
+
+def test_known_answers_mesh_hip():
+    s = 1.0 / np.tan(np.radians(30.0))
+    # KA2: unit sphere at d = 2.2 -> disc of NDC radius 1/(tan30 sqrt(d^2 - 1)) = 0.88388 -> 61.36 % of the pixels
+    v, f = syn.icosphere(5)
+    _, p2f = _hip_render_mesh(v, f, 30.0, 20.0, 2.2, 224)
+    assert abs((p2f >= 0).mean() - np.pi * 0.88388 ** 2 / 4) < 0.004
+    # KA3: lattice-aligned fronto-parallel right triangle: exactly the pixel centres with all barycentrics > 0
+    S, d = 16, 2.0
+    ndc = np.array([[-0.75, -0.75], [0.75, -0.75], [-0.75, 0.75]])
+    world = np.stack([-ndc[:, 0] * d / s, ndc[:, 1] * d / s, np.zeros(3)], 1)
+    _, p2f = _hip_render_mesh(*_tris([world]), 0.0, 0.0, d, S, persp=False)
+    c = -1 + (2 * np.arange(S) + 1) / S
+    X, Y = np.meshgrid(c[::-1], c[::-1])           # output (row i, col j) <-> (x, y) = (c[S-1-j], c[S-1-i])
+    assert np.array_equal(p2f >= 0, (X > -0.75) & (Y > -0.75) & (X + Y < 0.0))
+    # KA4: coincident faces -> the lower index wins; a nearer face beats a lower index
+    tri = [[-0.5, -0.5, 0.0], [0.5, -0.5, 0.0], [0.0, 0.6, 0.0]]
+    near = [[-0.5, -0.5, 0.3], [0.5, -0.5, 0.3], [0.0, 0.6, 0.3]]
+    assert set(np.unique(_hip_render_mesh(*_tris([tri, tri, tri]), 0.0, 0.0, 2.2, 32)[1])) == {-1, 0}
+    assert set(np.unique(_hip_render_mesh(*_tris([tri, near]), 0.0, 0.0, 2.2, 32)[1])) == {-1, 1}
+    # KA5 + KA6: constant-normal plane, closed-form Phong; background pixels carry the background colour exactly
+    quad_v = np.asarray([[-2, -2, 0], [2, -2, 0], [2, 2, 0], [-2, 2, 0]], np.float32)
+    quad_f = np.asarray([[0, 1, 2], [0, 2, 3]], np.int64)
+    col = 0.99999
+    cen = -1 + (2 * np.arange(8) + 1) / 8
+    for light, cosang in (((0.0, 1.0, 0.0), 0.0), ((0.0, 0.0, 1.0), 1.0), ((0.0, 1.0, 1.0), np.sqrt(0.5))):
+        img, p2f = _hip_render_mesh(quad_v, quad_f, 0.0, 0.0, 2.2, 8, light=light, obj=(col,) * 3, bg=(0.25, 0.5, 0.75))
+        assert (p2f >= 0).mean() > 0.8
+        checked = 0
+        for i in range(8):
+            for j in range(8):
+                if p2f[i, j] < 0:
+                    assert tuple(img[:, i, j]) == (0.25, 0.5, 0.75)
+                    continue
+                p = np.array([-cen[7 - j] * 2.2 / s, cen[7 - i] * 2.2 / s, 0.0])
+                vh = np.array([0, 0, 2.2]) - p
+                vh /= np.linalg.norm(vh)
+                l = np.asarray(light, float) / np.linalg.norm(light)
+                r = -l + 2 * cosang * np.array([0, 0, 1.0])
+                alpha = max(0.0, float(vh @ r)) * (1.0 if cosang > 0 else 0.0)
+                want = (0.5 + 0.3 * max(0.0, cosang)) * col + 0.2 * alpha ** 64
+                assert np.abs(img[:, i, j] - want).max() < 2e-5, (light, i, j)
+                checked += 1
+        assert checked > 50
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_random_configurations_slice(oracle, seed):
+    """A seeded slice of tests/stress_parity.py inside the suite: random anisotropically scaled / shifted meshes,
+    views anywhere on the sphere, cameras from inside the bounding sphere (dist 0.9: vertices behind the camera,
+    faces crossing z = 0, NDC coordinates far outside the screen) to 3.0, odd image sizes and strip heights, both
+    PyTorch3D switch settings.  Pixel->face maps bit-exact; colours within TOL_PIXEL on well-conditioned pixels."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    rng = np.random.default_rng(seed)
+    for case in range(4):
+        B, V = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        size = int(rng.choice([32, 45, 64, 100, 128]))
+        strip = int(rng.choice([0, 0, 3, 5, 8]))
+        persp, cull = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
+        vl, fl = [], []
+        for b in range(B):
+            v, f = syn.cad_soup(int(rng.integers(0, 1000))) if rng.integers(0, 4) == 0 else \
+                syn.synthetic_mesh(str(rng.choice(["S", "M"])), int(rng.integers(0, 1000)))
+            vl.append((v * rng.uniform(0.5, 1.3, 3) + rng.uniform(-0.2, 0.2, 3)).astype(np.float32))
+            fl.append(f)
+        az = rng.uniform(-180, 180, (B, V)).astype(np.float32)
+        el = rng.uniform(-80, 80, (B, V)).astype(np.float32)
+        di = rng.uniform(0.9, 3.0, (B, V)).astype(np.float32)
+        if case == 0:
+            di[:] = 0.9                      # always include the camera-inside-the-object case
+        obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
+        want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, perspective_correct=persp,
+                                    cull_backfaces=cull, mode=1)
+        packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+        R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+        # z_clip = 0: the no-clipping rule on both sides, so that faces crossing the near region stay comparable bit for bit
+        params = F.mesh_params(V, size, 1, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip, z_clip=0.0)
+        img, p2f = F.render_meshes_fragments(packed, R, T, _t([[0, 1, 0]]), params)
+        p2f, img = p2f.cpu().numpy(), img.cpu().numpy()
+        assert np.array_equal(p2f, want["pix_to_face"]), (seed, case, int((p2f != want["pix_to_face"]).sum()))
+        well = _well_conditioned_pixels(vl, fl, want["pix_to_face"], V)
+        diff = np.abs(img - want["images"]).reshape(B * V, 3, size, size).max(1)
+        assert float(diff[well].max()) <= TOL_PIXEL, (seed, case, float(diff[well].max()))
+
+
+@pytest.mark.parametrize("name,specs,V,size,dist,jitter", [
+    ("C2 slice", [("M", 0), ("M", 1), ("M", 2), ("M", 3)], 12, 224, 2.2, False),
+    ("tier L, 20 views", [("L", 2), ("L", 3)], 20, 224, 2.2, True),
+    ("ragged + CAD soup", [("S", 3), ("L", 4), ("soup", 5), ("M", 6)], 6, 224, 2.2, True),
+    ("close-up", [("M", 0), ("M", 1)], 12, 224, 1.2, True),
+    ("camera inside the object", [("M", 0), ("M", 1)], 12, 224, 0.8, True),
+    ("odd image size", [("S", 10), ("soup", 11)], 2, 37, 2.2, True),
+    ("128", [("M", 7)], 4, 128, 2.2, False),
+])
+def test_fast_rasteriser_equals_exact_kernel(name, specs, V, size, dist, jitter):
+    """The default mesh forward (k_mesh_raster_fast: fall-back to the exact body per strip) against MVR_RASTER_EXACT_ONLY
+    (k_mesh_raster_shade on every strip): pixel->face maps identical, images within the colour tolerance (the two shade
+    with differently ordered but equivalent arithmetic), and the number of strips the fast path gave up on."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = _mesh_batch(specs)
+    B = len(vl)
+    az, el, di = _views(B, V if V in (4, 6, 12, 20) else 4, 7, jitter)
+    az, el = az[:, :V], el[:, :V]
+    di = np.full((B, V), dist, np.float32) + (di[:, :V] - 2.2 if jitter else 0)
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
+    obj = bg = (0.99999,) * 3
+    out = {}
+    for mode in ("fast", "exact"):
+        params = F.mesh_params(V, size, 1, obj, bg, exact_raster=(mode == "exact"))
+        img, p2f, cnt = F.render_meshes_fragments(packed, R, T, light, params, return_redo=True)
+        torch.cuda.synchronize()
+        out[mode] = (img.cpu().numpy(), p2f.cpu().numpy(), int(cnt.item()))
+    n_strips = B * V * ((size + 7) // 8)
+    print("%s: %d of %d strips fell back to the exact rasteriser" % (name, out["fast"][2], n_strips))
+    assert np.array_equal(out["fast"][1], out["exact"][1]), "%d pixels differ" % int((out["fast"][1] != out["exact"][1]).sum())
+    assert np.abs(out["fast"][0] - out["exact"][0]).max() <= 5e-5
+    if "soup" not in str(specs) and dist >= 1.6:   # (nearer than 1.5 the clip plane z = 0.5 cuts faces: those views take the exact path)
+        assert out["fast"][2] <= n_strips // 100, "ordinary meshes should almost never need the exact path"
+    if "soup" in str(specs) and size % 2 == 0:   # (odd widths take the exact kernel: nothing to settle)
+        # coincident double-sided faces: undecidable for the affine depth keys.  Rounds 2-4 handed such strips to the exact kernel's
+        # body; round 5 settles the recorded (pixel, face) candidates inside the fast kernel (mvr_mesh_fast_stats counts them)
+        _, _, st = F.render_meshes_fragments(packed, R, T, light, F.mesh_params(V, size, 1, obj, bg), return_stats=True)
+        st = [int(x) for x in st.cpu()]
+        assert st[1] > 0 and st[0] <= n_strips // 50, st   # (a strip whose candidates overflow their area is still redone; which one depends on the list order of the run)
+
+
+def test_full_size_c2_all_meshes_against_the_oracle(oracle):
+    """BASELINE configs[1] at FULL size: all 16 tier-M meshes x 12 spherical views at 224^2 against the oracle
+    (round 1 checked a 2-mesh slice): pixel->face bit-exact, images within 1e-4."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    B, V, size = 16, 12, 224
+    vl, fl = _mesh_batch([("M", s) for s in range(B)])
+    az, el, di = _views(B, V, 0, jitter=False)
+    obj = bg = (0.99999,) * 3
+    want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, mode=1)
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    params = F.mesh_params(V, size, 1, obj, bg)
+    img, p2f = F.render_meshes_fragments(packed, R, T, _t(np.array([[0.0, 1.0, 0.0]], np.float32)), params)
+    torch.cuda.synchronize()
+    assert np.array_equal(p2f.cpu().numpy(), want["pix_to_face"])
+    assert np.abs(img.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+
+
+def test_prepass_lists_of_very_large_face_counts(oracle):
+    """The pre-pass keeps a thread's first 8 faces in registers and the records of later ones in LDS as far as it has
+    room; a face's first row-bin hands it a 15-bit rank.  Beyond those limits: (a) 40 960 faces over the image and 98 304
+    within a few rows, two views each (the last faces have no LDS record: every bin of theirs takes an atomic in the fill
+    pass); (b) one view of 61 440 faces, all nearer than the origin and inside one strip: >= 32 767 ranked faces in one
+    counter, so the view gets no strip lists and every strip is scanned by the exact path.  Faces are duplicated
+    (coincident: the (z, face index) tie rule decides).  Pixel -> face bit-exact against the oracle.
+    (Round 5: the lists are built in one pass into per-strip regions of at most 4 096 entries; a strip that needs more — here
+    the ONE strip that holds all 61 440 faces of case (b), and the strips of case (a)'s 98 304-face mesh — is scanned by the
+    exact path, the other strips of the view keep their lists.)"""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    v, f = syn.synthetic_mesh("L", 3)
+    size = 64
+    obj = bg = (0.99999,) * 3
+    light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
+    f5 = np.concatenate([f, f[:, [1, 2, 0]], f[::-1], f[:, [2, 0, 1]], f])
+    vs, _ = syn.synthetic_mesh("S", 4)
+    cases = [([v, (v * 0.08 + np.array([0.0, 0.2, 0.0])).astype(np.float32)], [np.concatenate([f, f[::-1]])[:40960], f5[:98304]],
+              _views(2, 2, 31), None),
+             # camera on the +z axis; the object sits between it and the origin, ~6 rows tall, inside the strip of rows 16-23
+             ([(v[:1500] * 0.08 + np.array([0.0, 0.36, 0.6])).astype(np.float32)], [np.random.default_rng(5).integers(0, 1500, (61440, 3))],
+              (np.zeros((1, 1), np.float32), np.zeros((1, 1), np.float32), np.full((1, 1), 2.2, np.float32)), 1)]
+    for vl, fl, (az, el, di), want_redo in cases:
+        B, V = az.shape
+        want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, mode=1)
+        packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(x) for x in vl], [torch.from_numpy(np.ascontiguousarray(x)) for x in fl]), _dev())
+        R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+        for exact in (False, True):
+            params = F.mesh_params(V, size, 1, obj, bg, exact_raster=exact)
+            img, p2f, redo = F.render_meshes_fragments(packed, R, T, light, params, return_redo=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(p2f.cpu().numpy(), want["pix_to_face"]), exact
+            assert np.abs(img.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+            if want_redo is not None and not exact:
+                assert int(redo) == want_redo, int(redo)   # the one overflowed strip went to the exact path (which scans for it)
+        assert all((want["pix_to_face"][b * V:(b + 1) * V] >= 0).sum() > 0 for b in range(B))
+
+
+def test_custom_vertex_colours_with_a_packed_batch(oracle):
+    """object_color="custom" + a pre-packed PackedMeshes: the per-vertex colours must reach the kernel (they
+    were dropped and the image came out white); same image as handing the list of meshes."""
+    from mvtn_amd import MVRenderer, Meshes, PackedMeshes
+    vl, fl = _mesh_batch([("S", 0), ("S", 1)])
+    B, V, size = 2, 3, 64
+    rng = np.random.default_rng(3)
+    mx = max(len(v) for v in vl)
+    col = rng.uniform(0.1, 0.9, (B, mx, 3)).astype(np.float32)
+    az, el, di = _views(B, 4, 2)
+    az, el, di = az[:, :V], el[:, :V], di[:, :V]
+    r = MVRenderer(V, size, pc_rendering=False, object_color="custom", light_direction="fixed").eval()
+    meshes = [Meshes([v], [f]) for v, f in zip(vl, fl)]
+    a, e, d, c = _t(az), _t(el), _t(di), _t(col)
+    img_list, _ = r(meshes, None, a, e, d, c)
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    img_packed, _ = r(packed, None, a, e, d, c)
+    assert torch.equal(img_list, img_packed)
+    vc = np.concatenate([col[b, :len(v)] for b, v in enumerate(vl)], 0)
+    want = oracle.render_meshes(vl, fl, az, el, di, size, vert_colors=vc, bg_color=(0.99999,) * 3)
+    assert np.abs(img_packed.cpu().numpy() - want["images"]).max() <= TOL_PIXEL
+    assert float((img_packed - 0.99999).abs().max()) > 0.05      # not a white render
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_z_clip_cuts_faces_like_the_reference(oracle, exact):
+    """PyTorch3D >= 0.5 clips faces at view depth znear / 2 = 0.5 (SURVEY A.9 ii; active as soon as transform_distance
+    lets dist drop towards 1.1, models/mvtn.py:33,68,109): faces wholly nearer than the plane disappear, faces that
+    straddle it are cut into one or two triangles.  Against the oracle's clip_faces restatement: pixel -> face map
+    bit-exact and images within tolerance at dist 2.2 (nothing to cut), 1.1 and 0.9 (camera inside the bounding sphere:
+    vertices behind the camera, faces cut on both sides), with and without back-face culling, through the default
+    forward (views with cut faces fall back to the exact kernel per strip) and the exact-only kernel; the count of cut
+    faces equals the oracle's; z_clip = 0 switches the rule off."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = _mesh_batch([("M", 0), ("S", 4), ("soup", 2)])
+    B, V, size = 3, 4, 96
+    az, el, _ = _views(B, 4, 3)
+    obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
+    light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
+    packed = PackedMeshes.from_meshes(Meshes(vl, fl), _dev())
+    for dist, cull, expect_cut in ((2.2, False, False), (1.1, False, True), (1.1, True, True), (0.9, False, True)):
+        di = np.full((B, V), dist, np.float32)
+        R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+        params = F.mesh_params(V, size, 1, obj, bg, cull_backfaces=cull, exact_raster=exact)   # z_clip = None -> 0.5 (perspective_correct)
+        assert abs(params.z_clip - 0.5) < 1e-12
+        img, p2f, ns = F.render_meshes_fragments(packed, R, T, light, params, return_straddlers=True)
+        want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, z_clip=0.5, cull_backfaces=cull, mode=1)
+        assert int(ns.item()) == int(want["straddlers"].sum())
+        assert (int(ns.item()) > 0) == expect_cut
+        p2f, img = p2f.cpu().numpy(), img.cpu().numpy()
+        assert np.array_equal(p2f, want["pix_to_face"]), (dist, cull, int((p2f != want["pix_to_face"]).sum()))
+        well = _well_conditioned_pixels(vl, fl, want["pix_to_face"], V)
+        diff = np.abs(img - want["images"]).reshape(B * V, 3, size, size).max(1)
+        assert float(diff[well].max()) <= TOL_PIXEL, (dist, cull, float(diff[well].max()))
+        if expect_cut:   # and the rule can be switched off
+            off = F.mesh_params(V, size, 1, obj, bg, cull_backfaces=cull, z_clip=0.0, exact_raster=exact)
+            img0, p2f0, ns0 = F.render_meshes_fragments(packed, R, T, light, off, return_straddlers=True)
+            legacy = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, z_clip=0.0, cull_backfaces=cull, mode=1)
+            assert int(ns0.item()) == 0 and np.array_equal(p2f0.cpu().numpy(), legacy["pix_to_face"])
+            assert not np.array_equal(legacy["pix_to_face"], want["pix_to_face"])
+
+
+def test_hip_path_against_the_torch_restatement_of_c1():
+    """The HIP path against the second, torch-made implementation of BASELINE configs[0] directly (no C oracle in between;
+    tests/golden/torch_restatement_c1.npz): pixel -> face identical up to a handful of edge pixels, colours within 1e-4."""
+    import os
+    from mvtn_amd import MVRenderer, Meshes, functional as F
+    from mvtn_amd.structures import PackedMeshes
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "torch_restatement_c1.npz"))
+    v, f = syn.synthetic_mesh(str(fx["mesh"][0]), int(fx["mesh"][1]))
+    S, V = int(fx["image_size"]), 4
+    packed = PackedMeshes.from_meshes(Meshes([v], [f]), _dev())
+    R, T = F.look_at_view_transform(_t(fx["dist"]), _t(fx["elev"]), _t(fx["azim"]))
+    assert np.abs(R.cpu().numpy() - fx["R"]).max() <= 2.5e-7
+    params = F.mesh_params(V, S, 1, (0.99999,) * 3, (0.99999,) * 3)
+    img, p2f = F.render_meshes_fragments(packed, R, T, _t(np.array([[0.0, 1.0, 0.0]], np.float32)), params)
+    differ = p2f.cpu().numpy() != fx["pix_to_face"].astype(np.int32)
+    assert differ.sum() <= 8
+    assert np.abs(img.cpu().numpy()[0] - fx["images"]).max(1)[~differ].max() <= TOL_PIXEL
+    r = MVRenderer(V, S, pc_rendering=False, light_direction="fixed").eval()
+    img2, _ = r([Meshes([v], [f])], None, _t(fx["azim"][None]), _t(fx["elev"][None]), _t(fx["dist"][None]))
+    assert torch.equal(img2, img)
+
+
+def test_hip_face_clipping_against_the_torch_restatement():
+    """clip_faces / convert_clipped_rasterization_to_original_faces as torch ops (dist 1.1: 65 and 63 faces cut) vs the HIP
+    path: same counts of cut faces, pixel -> face identical at every pixel, colours within 1e-4."""
+    from mvtn_amd import Meshes, functional as F
+    from mvtn_amd.structures import PackedMeshes
+    fx = _fx("torch_restatement_zclip.npz")
+    v, f = syn.synthetic_mesh(str(fx["mesh"][0]), int(fx["mesh"][1]))
+    S, V = int(fx["image_size"]), len(fx["azim"])
+    packed = PackedMeshes.from_meshes(Meshes([v], [f]), _dev())
+    R, T = F.look_at_view_transform(_t(fx["dist"]), _t(fx["elev"]), _t(fx["azim"]))
+    for exact in (False, True):
+        params = F.mesh_params(V, S, 1, (0.99999,) * 3, (0.99999,) * 3, z_clip=float(fx["z_clip"]), exact_raster=exact)
+        img, p2f, n_st = F.render_meshes_fragments(packed, R, T, _t(np.array([[0.0, 1.0, 0.0]], np.float32)), params, return_straddlers=True)
+        assert int(n_st) == int(fx["straddlers"].sum())
+        differ = p2f.cpu().numpy() != fx["pix_to_face"].astype(np.int32)
+        assert differ.sum() == 0, differ.sum()   # (observed: 0 of 32 768 pixels)
+        assert np.abs(img.cpu().numpy()[0] - fx["images"]).max(1)[~differ].max() <= TOL_PIXEL
+
+
+def test_library_switches_follow_the_oracle_switches(oracle):
+    """MVRenderer(fov_scale=..., normals_three_cross=True) (mvr_mesh_params.fov_scale, MVR_NORMALS_THREE_CROSS) against the
+    oracle with the same switches: pixel -> face maps bit-exact, colours within 1e-4; and each switch changes something."""
+    from mvtn_amd import MVRenderer, Meshes
+    v, f = syn.synthetic_mesh("M", 4)
+    V, size = 4, 96
+    az, el, di = _views(1, V, 3)
+    s1 = float.fromhex("0x1.bb67b0p+0")
+    kw = dict(obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
+    outs = {}
+    for name, three, s in (("default", True, 0.0), ("one_cross", False, 0.0), ("fov_scale", True, s1)):
+        try:
+            oracle.set_options(three, s)
+            want = oracle.render_meshes([v], [f], az, el, di, size, **kw)
+        finally:
+            oracle.set_options()
+        r = MVRenderer(V, size, pc_rendering=False, object_color="white", background_color="white", light_direction="fixed",
+                       fov_scale=s, normals_three_cross=three).eval()
+        a, e, d = (_t(x).requires_grad_(True) for x in (az, el, di))
+        img, _ = r([Meshes([v], [f])], None, a, e, d)
+        err = float(np.abs(img.detach().cpu().numpy() - want["images"]).max())
+        assert err <= TOL_PIXEL, (name, err)
+        img.sum().backward()
+        assert torch.isfinite(a.grad).all() and float(a.grad.abs().max()) > 0
+        outs[name] = (img.detach().cpu().numpy(), want["images"])
+    assert 0 < np.abs(outs["one_cross"][0] - outs["default"][0]).max() < 1e-5      # normals: colours move in the 7th digit
+    assert np.abs(outs["fov_scale"][0] - outs["default"][0]).max() > 0                # s one ulp larger: the image changes
+    # the HIP path follows the oracle THROUGH the switch (not merely both within tolerance of the default)
+    d_hip, d_orc = outs["one_cross"][0] - outs["default"][0], outs["one_cross"][1] - outs["default"][1]
+    assert np.abs(d_hip - d_orc).max() < 5e-6
+
+
+@pytest.mark.parametrize("size,strip_rows,tier", [(224, 0, "L"), (224, 16, "L"), (256, 16, "L"), (256, 32, "M"), (100, 5, "L"), (64, 32, "L"), (37, 3, "M")])
+def test_fast_rasteriser_lds_layouts_against_the_exact_kernel(size, strip_rows, tier):
+    """The fast rasteriser's shading table runs over the key, record and item areas of the workgroup's LDS and the
+    covered-pixel list carries 32-bit entries; both are sized from the strip's shape.  Other strip shapes than the
+    default 224 x 8 — and dense meshes, whose strips need several table passes — against the exact kernel: identical
+    pixel -> face maps, colours within the two kernels' shading tolerance."""
+    from mvtn_amd import functional as F
+    from mvtn_amd.structures import Meshes, PackedMeshes
+    vl, fl = zip(*[syn.synthetic_mesh(tier, 40 + i) for i in range(2)])
+    V = 6
+    az, el, di = _views(2, V, 11)
+    packed = PackedMeshes.from_meshes(Meshes([torch.from_numpy(v) for v in vl], [torch.from_numpy(f) for f in fl]), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    light = _t(np.array([[0.0, 1.0, 0.0]], np.float32))
+    out = {}
+    for mode in ("fast", "exact"):
+        params = F.mesh_params(V, size, 1, (0.9, 0.8, 0.7), (1.0, 1.0, 1.0), exact_raster=(mode == "exact"), strip_rows=strip_rows)
+        img, p2f, cnt = F.render_meshes_fragments(packed, R, T, light, params, return_redo=True)
+        torch.cuda.synchronize()
+        out[mode] = (img.cpu().numpy(), p2f.cpu().numpy(), int(cnt.item()))
+    assert (out["exact"][1] >= 0).mean() > 0.1, "the object must cover part of the frame"
+    assert np.array_equal(out["fast"][1], out["exact"][1]), "%d pixels differ" % int((out["fast"][1] != out["exact"][1]).sum())
+    assert np.abs(out["fast"][0] - out["exact"][0]).max() <= 5e-5
+
+
+@pytest.mark.parametrize("S", [96, 95])
+def test_fast_rasteriser_faces_with_tiny_edge_coefficients(S):
+    """(S = 95, ADVICE r4: an odd width has a pixel centre at exactly 0, outside fast_coef_tiny's proof — odd widths take the exact
+    kernel; the case stays here so that a future fast path for them meets these faces.)  Round 4: the fast rasteriser no longer tests every inside pixel for an edge value in (0, 2^-100); a face with a nonzero
+    edge coefficient below 2^-44 — the only kind that can produce one (mvr_mesh_raster_fast.inc: fast_coef_tiny) — is not
+    trusted and its pixels are settled by the exact test.  Triangles with an edge that is almost, but not exactly, horizontal or
+    vertical (coordinate differences of 1e-20 ... 1e-30 after an axis-aligned camera), in front of and behind ordinary ones:
+    pixel -> face maps identical to the oracle's and to the exact kernel's."""
+    from mvtn_amd import Meshes, functional as F
+    from mvtn_amd.structures import PackedMeshes
+    from oracle import oracle
+    v = np.array([[-0.5, 0.0, 0.1], [0.5, 1e-20, 0.1], [0.0, 0.6, 0.1],          # nearly horizontal edge (dy = 1e-20)
+                  [0.0, -0.5, -0.2], [1e-25, 0.5, -0.2], [0.45, 0.0, -0.2],   # nearly vertical edge (dx = 1e-25)
+                  [-0.6, 0.0, 0.3], [0.6, 1e-30, 0.3], [0.1, -0.55, 0.3],   # another one, nearest to the camera
+                  [-0.7, -0.7, -0.4], [0.7, -0.7, -0.4], [0.0, 0.7, -0.4]], np.float32)   # an ordinary triangle behind them
+    f = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]], np.int64)
+    az, el, di = np.array([[0.0, 180.0]], np.float32), np.array([[0.0, 0.0]], np.float32), np.array([[2.2, 2.2]], np.float32)
+    want = oracle.render_meshes([v], [f], az, el, di, S, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3)
+    packed = PackedMeshes.from_meshes(Meshes([v], [f]), _dev())
+    R, T = F.look_at_view_transform(_t(di.reshape(-1)), _t(el.reshape(-1)), _t(az.reshape(-1)))
+    light = _t([[0.0, 1.0, 0.0]])
+    maps = {}
+    for mode in ("fast", "exact"):
+        params = F.mesh_params(2, S, 1, (0.99999,) * 3, (0.99999,) * 3, exact_raster=(mode == "exact"))
+        img, p2f = F.render_meshes_fragments(packed, R, T, light, params)
+        maps[mode] = p2f.cpu().numpy()
+        assert (maps[mode] != want["pix_to_face"]).sum() == 0, mode
+        assert np.abs(img.cpu().numpy() - want["images"]).max() <= 1e-4, mode
+    assert (want["pix_to_face"] >= 0).mean() > 0.1      # the triangles are on screen
+
+
+@pytest.mark.parametrize("size", [224, 128])
+def test_cad_meshes_pix_to_face_bit_exact(oracle, size):
+    """Two CAD-like objects x the 12 spherical views of C2 (and at 128 x 128): coincident reversed shells (the (z, face index) tie
+    of SURVEY A.4 decides every pixel of them), faces wider than 16 pixels (the wave-per-face path), slivers, interior parts."""
+    oracle.set_threads(8)
+    vl, fl = zip(*[syn.cad_mesh(s) for s in (0, 1)])
+    az, el, di = (np.tile(x, (2, 1)) for x in syn.spherical_views(12))
+    want, want_default, touch = _oracle_both_normal_sums(oracle, list(vl), list(fl), az, el, di, size)
+    img, p2f, st = _render(list(vl), list(fl), az, el, di, size)
+    print("cad %d^2: strips redone %d, ambiguous pixels %d, wide entries %d of %d; pixels on faces with a cancelled vertex normal %d of %d covered" % (
+        size, st[0], st[1], st[2], st[3], touch.sum(), (p2f >= 0).sum()))
+    assert (p2f != want["pix_to_face"]).sum() == 0
+    assert np.abs(img - want["images"]).max() <= 1e-4                      # order-independent normal sums: every pixel
+    d_def = np.abs(img - want_default["images"]).reshape(2 * 12, 3, size, size).max(axis=1)
+    assert d_def[~touch].max() <= 1e-4                                       # face-order float sums: every pixel that is a function of the input
+    assert touch.sum() > 1000 and (d_def[touch] > 1e-4).any()               # (the masked set is what the docstring says, and it matters)
+    assert st[2] > 0 and st[3] > 0          # the wave-per-face path ran
+    # the exact kernel on the same input: the same map (what the fast one falls back to)
+    img_e, p2f_e, _ = _render(list(vl), list(fl), az, el, di, size, exact_raster=True)
+    assert np.array_equal(p2f_e, p2f) and np.abs(img_e - img).max() <= 5e-5
+
+
+def test_ragged_batch_pix_to_face_bit_exact(oracle):
+    """A ragged batch (tiers S, M, L, M: 1 280 / 5 120 / 20 480 / 5 120 faces) x 12 views at 224 x 224."""
+    oracle.set_threads(8)
+    vl, fl = zip(*[syn.geometry_mesh("ragged", "M", i) for i in range(4)])
+    assert [len(f) for f in fl] == [1280, 5120, 20480, 5120]
+    az, el, di = (np.tile(x, (4, 1)) for x in syn.spherical_views(12))
+    want = oracle.render_meshes(list(vl), list(fl), az, el, di, 224, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, mode=1)
+    img, p2f, st = _render(list(vl), list(fl), az, el, di, 224)
+    print("ragged: strips redone %d, ambiguous pixels %d, wide entries %d of %d" % tuple(st))
+    assert (p2f != want["pix_to_face"]).sum() == 0
+    assert np.abs(img - want["images"]).max() <= 1e-4
+
+
+def test_hip_against_torch_restatement_on_cad_and_ragged_meshes(oracle):
+    """the HIP path against the torch-made second implementation (make_torch_restatement_r5.py) on a CAD-like
+    object (forward: maps + images; backward: torch.autograd in float64 with the map held fixed, relative light) and on a ragged
+    tier-S / tier-M pair rendered as ONE batch (the packer's offsets)."""
+    import os
+    from mvtn_amd import Meshes, functional as F
+    from mvtn_amd.structures import PackedMeshes
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "torch_restatement_r5.npz"))
+    v, f = syn.cad_mesh(int(fx["cad_seed"]), n_faces=int(fx["cad_faces"]))
+    S = int(fx["cad_image_size"])
+    img, p2f, st = _render([v], [f], fx["cad_azim"][None], fx["cad_elev"][None], fx["cad_dist"][None], S)
+    want_map = fx["cad_pix_to_face"].astype(np.int32)
+    # (pixels on another face: only swaps between a face and its coincident reversed twin — the twin with the smaller depth wins
+    # by the last bit, and the fixture's vertices come from 4 x 4 bmm chains: tests/test_oracle.py, same fixture, same count)
+    differ = p2f != want_map
+    twin_key = lambda i: tuple(sorted(map(tuple, v[f[i]].tolist())))   # noqa: E731
+    n_twin = sum(1 for x, y in zip(p2f[differ], want_map[differ]) if x >= 0 and y >= 0 and twin_key(x) == twin_key(y))
+    want_orc = oracle.render_meshes([v], [f], fx["cad_azim"][None], fx["cad_elev"][None], fx["cad_dist"][None], S, mode=1)["pix_to_face"]
+    assert differ.sum() == n_twin and np.array_equal(p2f, want_orc)
+    # Round 6: with the library's two projection switches set to what the fixture's torch ops do — MVR_PROJECTION_FMA (world ->
+    # view accumulated like a batched matrix product) and fov_scale = torch's K[0][0] (+1 ulp of the double-rounded value) — the
+    # library's map equals the restatement's at EVERY pixel, coincident twins included (and the oracle's with switch #5 set).
+    s_torch = float.fromhex("0x1.bb67b0p+0")
+    _, p2f_fma, _ = _render([v], [f], fx["cad_azim"][None], fx["cad_elev"][None], fx["cad_dist"][None], S, projection_fma=True, fov_scale=s_torch)
+    oracle.set_projection_bmm(True)
+    oracle.set_options(True, s_torch)
+    try:
+        want_bmm = oracle.render_meshes([v], [f], fx["cad_azim"][None], fx["cad_elev"][None], fx["cad_dist"][None], S, mode=1)["pix_to_face"]
+    finally:
+        oracle.set_projection_bmm(False)
+        oracle.set_options()
+    print("cad object: pixels on another face than the torch restatement: %d with the default projection, %d with MVR_PROJECTION_FMA + torch's K[0][0]" % (
+        int(differ.sum()), int((p2f_fma != want_map).sum())))
+    assert np.array_equal(p2f_fma, want_bmm) and int((p2f_fma != want_map).sum()) == 0
+    face_c = oracle.cancelled_normal_vertices(v, f)[f].any(axis=1)
+    touch = np.where(want_map >= 0, face_c[np.maximum(want_map, 0)], False)
+    assert np.abs(img[0] - fx["cad_images"]).max(axis=1)[~touch & ~differ].max() <= 1e-4
+    # backward against torch.autograd: the gather kernel takes ANY pixel -> face map — it is handed the FIXTURE's, so that both
+    # sides differentiate the same function (on its own map the library picks the other twin of a coincident pair at 3 % of the
+    # shells' pixels, and a twin on duplicated vertices has the opposite normal).  The table kernel starts from the rasteriser's
+    # own pixel lists: it is compared with the gather kernel on the library's map in test_cad_batch_through_the_module_and_backward.
+    from mvtn_amd import _lib
+    lib = _lib.load()
+    az, el, di = (fx["cad_g_" + k].astype(np.float32) for k in ("azim", "elev", "dist"))
+    G = _t(np.random.default_rng(int(fx["cad_g_seed"])).standard_normal((1, 4, 3, S, S)).astype(np.float32))
+    packed = PackedMeshes.from_meshes(Meshes([v], [f]), _dev())
+    a, e, d = _t(az), _t(el), _t(di)
+    R, T = F.look_at_view_transform(d, e, a)
+    light = F.camera_position_from_spherical_angles(d, e, a)
+    params = F.mesh_params(4, S, 4, (0.99999,) * 3, (0.99999,) * 3, gather_backward=True)
+    mb = packed.c_struct()
+    ws_bytes = lib.mvr_mesh_workspace_bytes(mb, params)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=_dev())
+    images = torch.empty(1, 4, 3, S, S, device=_dev())
+    p2f_own = torch.empty(4, S, S, dtype=torch.int32, device=_dev())
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.mvr_render_meshes_forward(mb, params, R.data_ptr(), T.data_ptr(), light.data_ptr(), images.data_ptr(), p2f_own.data_ptr(),
+                                             ws.data_ptr(), ws_bytes, st), "forward")
+    p2f_fx = _t(fx["cad_g_pix_to_face"].astype(np.int32), torch.int32)
+    n_diff = int((p2f_own != p2f_fx).sum())
+    bparams = _lib.MeshParams.from_buffer_copy(params)
+    bparams.flags |= _lib.MVR_WORKSPACE_FROM_FORWARD
+    gR, gT, gL = torch.empty(4, 9, device=_dev()), torch.empty(4, 3, device=_dev()), torch.empty(4, 3, device=_dev())
+    _lib.check(lib.mvr_render_meshes_backward(mb, bparams, R.data_ptr(), T.data_ptr(), light.data_ptr(), p2f_fx.data_ptr(), G.data_ptr(),
+                                              gR.data_ptr(), gT.data_ptr(), gL.data_ptr(), ws.data_ptr(), ws_bytes, st), "backward")
+    g1, g2 = torch.empty(3, 4, device=_dev()), torch.empty(3, 4, device=_dev())
+    _lib.check(lib.mvr_look_at_backward(a.data_ptr(), e.data_ptr(), d.data_ptr(), 4, gR.data_ptr(), gT.data_ptr(), g1[0].data_ptr(), g1[1].data_ptr(),
+                                        g1[2].data_ptr(), st), "look_at_backward")
+    _lib.check(lib.mvr_camera_position_backward(a.data_ptr(), e.data_ptr(), d.data_ptr(), 4, gL.data_ptr(), g2[0].data_ptr(), g2[1].data_ptr(),
+                                                g2[2].data_ptr(), st), "camera_position_backward")
+    got = (g1 + g2).double().cpu().numpy()
+    for k, name in enumerate(("azim", "elev", "dist")):
+        ref = fx["cad_grad_" + name].astype(np.float64)
+        rel = np.abs(got[k] - ref).max() / np.abs(ref).max()
+        print("cad %s: max relative error %.2e against torch.autograd on the fixture's map (the library's own map differs at %d twin pixels)" % (name, rel, n_diff))
+        assert rel <= 5e-3, (name, rel, got[k], ref)
+    # Round 6: beside float32 torch.autograd on the same map (make_torch_restatement_grad32.py) — per
+    # derivative the library is off the float64 value by at most twice what the reference's own fp32 arithmetic is, + 2e-4
+    f32 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "torch_restatement_grad32.npz"))
+    for k, name in enumerate(("azim", "elev", "dist")):
+        ref = fx["cad_grad_" + name].astype(np.float64)
+        e_lib, e_t32 = np.abs(got[k] - ref) / np.abs(ref).max(), np.abs(f32["cad_grad_%s_f32" % name] - ref) / np.abs(ref).max()
+        print("cad %s: |library - f64| max %.2e, |torch f32 - f64| max %.2e (relative to the largest derivative)" % (name, e_lib.max(), e_t32.max()))
+        assert (e_lib <= 2.0 * e_t32 + 2e-4).all(), (name, e_lib, e_t32)
+    # the ragged pair as one batch
+    vs, fs = syn.synthetic_mesh("S", int(fx["rag_seeds"][0]))
+    vm, fm = syn.synthetic_mesh("M", int(fx["rag_seeds"][1]))
+    Sr = int(fx["rag_image_size"])
+    azr, elr, dir_ = (np.tile(fx["rag_" + k][None], (2, 1)).astype(np.float32) for k in ("azim", "elev", "dist"))
+    img, p2f, _ = _render([vs, vm], [fs, fm], azr, elr, dir_, Sr)
+    for b, name in enumerate(("rag_s", "rag_m")):
+        assert (p2f[3 * b:3 * b + 3] != fx[name + "_pix_to_face"].astype(np.int32)).sum() == 0, name
+        assert np.abs(img[b] - fx[name + "_images"]).max() <= 1e-4, name
+
+
+def test_untrusted_face_over_the_left_image_border(oracle):
+    """Round 5, found by tests/stress_parity.py as a GPU memory fault: a face of infinite tolerance (a nonzero edge coefficient below
+    2^-44: every pixel it touches is settled exactly) reports BOTH pixels of every pair — also the second pixel of a pair that starts
+    in the image's last column, which does not exist.  At pixel 0 of a strip that was index -1; the candidate list read it as pixel
+    8191 of list entry 2^19 and gathered from there.  Eight meshes whose big, nearly-axis-aligned triangle is shifted pixel by pixel
+    across the left border (either parity of its first column), two image sizes: maps bit-exact against the oracle."""
+    for S in (96, 64):
+        vl, fl = [], []
+        for k in range(16):
+            dx = (k % 8) * 2.2 * 2.0 / (S * 1.7320508)    # one pixel per step at the depth of the big triangle
+            sx = 1.0 if k < 8 else -1.0                    # (both borders: image column 0 is the one the fault needed)
+            v = np.array([[sx * (-0.9 + dx), 0.0, 0.1], [sx * 3.0, 1e-20, 0.1], [sx * 3.0, 0.9, 0.1],   # beyond the border; one edge with dy = 1e-20 (a coefficient of ~1e-20: not trusted)
+                          [-0.5, -0.5, -0.3], [0.5, -0.5, -0.3], [0.0, 0.6, -0.3]], np.float32)     # an ordinary triangle behind it
+            vl.append(v); fl.append(np.array([[0, 1, 2], [3, 4, 5]], np.int64))
+        az, el, di = np.zeros((16, 1), np.float32), np.zeros((16, 1), np.float32), np.full((16, 1), 2.2, np.float32)
+        want = oracle.render_meshes(vl, fl, az, el, di, S, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, mode=1)
+        img, p2f, st = _render(vl, fl, az, el, di, S)
+        assert (want["pix_to_face"][:, :, 0] == 0).any() and (want["pix_to_face"][:, :, S - 1] == 0).any()   # the big triangle reaches both borders
+        assert (p2f != want["pix_to_face"]).sum() == 0, S
+        assert np.abs(img - want["images"]).max() <= 1e-4
+        assert st[1] > 0                                           # its pixels went through the exact settle
+
+
+@pytest.mark.parametrize("size,strip,layers,redone", [(224, 0, 2, False), (224, 0, 6, True), (256, 16, 2, True), (256, 8, 2, False)])
+def test_stacks_of_coincident_faces_fill_the_candidate_area(oracle, size, strip, layers, redone):
+    """`layers` copies of one nearly frame-filling quad on top of each other, every second one with reversed winding (the (z, face index) tie
+    rule decides every pixel), a small triangle in front.  Two copies: every pixel of a strip is a candidate of the fast rasteriser's
+    exact settle, reserved by the waves' ballots (one LDS atomic per wave), compacted into the LDS work list.  Six copies: more
+    candidates than the gap of the strip's list region holds (round 6: the candidates live there; a mesh of few faces gets room for
+    2 per pixel, mesh_ws_layout).  256 pixels wide in 16-row strips: two copies already
+    leave more than the work list in LDS holds (3072 + 256 x 16 entries < 2 x 16 x 256; in 8-row strips it fits).  Those strips are
+    redone by the exact body in the same launch.  Maps
+    bit-exact against the oracle either way."""
+    q = np.array([[-1.25, -1.25, 0.0], [1.25, -1.25, 0.0], [1.25, 1.25, 0.0], [-1.25, 1.25, 0.0]], np.float32)   # (every vertex in front of the clip plane in all three views)
+    verts = [q for _ in range(layers)] + [np.array([[-0.3, -0.3, -0.4], [0.3, -0.3, -0.4], [0.0, 0.4, -0.4]], np.float32)]
+    faces = []
+    for k in range(layers):
+        o = 4 * k
+        faces += [[o, o + 1, o + 2], [o, o + 2, o + 3]] if k % 2 == 0 else [[o, o + 2, o + 1], [o, o + 3, o + 2]]
+    faces.append([4 * layers, 4 * layers + 1, 4 * layers + 2])
+    v, f = np.concatenate(verts, 0), np.asarray(faces, np.int64)
+    az, el, di = np.array([[0.0, 30.0, 180.0]], np.float32), np.array([[0.0, 20.0, -10.0]], np.float32), np.full((1, 3), 2.2, np.float32)
+    kw = dict(strip_rows=strip) if strip else {}
+    want = oracle.render_meshes([v], [f], az, el, di, size, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, mode=1)
+    img, p2f, st = _render([v], [f], az, el, di, size, **kw)
+    assert (p2f != want["pix_to_face"]).sum() == 0
+    assert (p2f >= 0).mean() > 0.6 and len(np.unique(p2f[0])) >= 3
+    assert np.abs(img - want["images"]).max() <= 1e-4
+    assert (st[0] > 0) == redone, st          # strips redone by the exact body
+    if not redone:
+        assert st[1] > 0.5 * (p2f >= 0).sum()  # candidates of the settle: about one per covered pixel and pair of copies
+
+
+def test_scheduling_hints_never_change_a_pixel(tmp_path):
+    """the wave priorities (s_setprio) of the mesh rasterisers and the start stagger (s_sleep) of the point
+    rasteriser are timing hints.  A library built with -DMVR_NO_TUNING (they are compiled out) renders the same bits: mesh and
+    point frames at 128, 224 and 448 pixels, each library in a process of its own (MVR_LIB selects it)."""
+    import os
+    import subprocess
+    import sys
+    from mvtn_amd import build as b
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = str(tmp_path / "libmvr_no_tuning.so")
+    b.build_hip(out=variant, extra_flags=["-DMVR_NO_TUNING"])
+    script = tmp_path / "render.py"
+    script.write_text(_TUNING_SCRIPT)
+    outs = {}
+    for name, lib in (("product", b.LIB_PATH), ("no_tuning", variant)):
+        path = str(tmp_path / (name + ".npz"))
+        env = dict(os.environ, MVR_LIB=lib)
+        r = subprocess.run([sys.executable, str(script), root, path], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(path)
+    for k in outs["product"].files:
+        a, c = outs["product"][k], outs["no_tuning"][k]
+        assert (a != 0.99999).any(), k                 # something was drawn
+        assert np.array_equal(a, c), k

@@ -171,8 +171,10 @@ def test_flag_constants_and_workspace_rules_without_gpu():
     header = open(os.path.join(ROOT, "include", "mvr.h")).read()
     enum = dict((k, int(v)) for k, v in re.findall(r"\b(MVR_[A-Z_]+)\s*=\s*(\d+)", header))
     for name in ("MVR_CULL_BACKFACES", "MVR_PERSPECTIVE_CORRECT", "MVR_WORKSPACE_FROM_FORWARD", "MVR_RASTER_EXACT_ONLY",
-                 "MVR_BACKWARD_GATHER", "MVR_KEEP_PIXEL_LISTS"):
+                 "MVR_BACKWARD_GATHER", "MVR_KEEP_PIXEL_LISTS", "MVR_NORMALS_THREE_CROSS", "MVR_PROJECTION_FMA"):
         assert getattr(_lib, name) == enum[name], name
+    assert F.mesh_params(12, 224, 1, (1, 1, 1), (1, 1, 1), projection_fma=True).flags & _lib.MVR_PROJECTION_FMA
+    assert not F.mesh_params(12, 224, 1, (1, 1, 1), (1, 1, 1)).flags & _lib.MVR_PROJECTION_FMA   # the default is the closed form
     flags = [enum[k] for k in ("MVR_CULL_BACKFACES", "MVR_PERSPECTIVE_CORRECT", "MVR_WORKSPACE_FROM_FORWARD", "MVR_RASTER_EXACT_ONLY",
                                "MVR_BACKWARD_GATHER", "MVR_KEEP_PIXEL_LISTS")]
     assert sorted(flags) == [1, 2, 4, 8, 16, 32]
@@ -201,6 +203,30 @@ def test_flag_constants_and_workspace_rules_without_gpu():
                 setattr(p, k, v)
             assert call(p) == 1, fields
             assert any(w in lib.mvr_last_error() for w in (b"win_", b"reserved2_", b"fov_scale")), (fields, lib.mvr_last_error())
+
+
+def test_mesh_workspace_sizes_without_gpu():
+    """Round 6: what a mesh forward asks its caller to allocate.  The settle's candidates live
+    in the gap of the strips' list regions (round 5: an area of their own, 16 B per pixel per view): C2 (16 tier-M meshes x 12 views,
+    224 x 224) 387 -> 271 MB, all of C5 on one GPU 3.68 -> 2.36 GB.  No list regions where the pre-pass cannot build lists (more
+    than 254 strips; the comment in mesh_ws_layout used to call them 'address space': callers commit every byte)."""
+    from mvtn_amd import _lib, functional as F
+    lib = _lib.load()
+
+    def ws(B, V, nv, nf, size, **kw):
+        mb = _lib.MeshBatch(B, B * nv, B * nf, nf, nv, 0, 1, 1, 1, 1, None)
+        return lib.mvr_mesh_workspace_bytes(mb, F.mesh_params(V, size, 1, (1, 1, 1), (1, 1, 1), **kw))
+    c2, c5 = ws(16, 12, 2562, 5120, 224), ws(64, 20, 10242, 20480, 224)
+    print("workspace: C2 %.1f MB, all of C5 %.2f GB" % (c2 / 1e6, c5 / 1e9))
+    assert c2 <= 280e6 and c5 <= 2.4e9
+    # per (view, strip) a region of half the faces + a quarter entry per pixel, 16 B per entry (tier M at 224 x 8: 3 008 entries)
+    assert abs(c2 - 16 * 12 * 28 * 3008 * 16) <= 16e6
+    # 2 400 rows in strips of 8 = 300 strips > 254: no strip lists -> no regions: the workspace is the per-vertex / per-face tables
+    tall = ws(2, 2, 2562, 5120, 2400, strip_rows=8)
+    assert tall <= 4 * (2562 * 16 * 4 + 5120 * 2) + 4 * 300 * 128 + 2 * 2562 * (24 + 32) + 65536, tall
+    # a mesh of few faces still gets room for two candidates per pixel of a strip (one doubled quad over the whole image)
+    tiny = ws(1, 1, 8, 5, 224)
+    assert tiny >= 28 * (5 + 224 * 8) * 16
 
 
 def test_product_has_no_cpu_fallback_and_never_imports_the_oracle():

@@ -621,3 +621,71 @@ def test_oracle_normal_sum_switch_changes_only_cancelled_vertices(oracle):
         assert canc.any() == expect_cancelled
         touch = np.where(a["pix_to_face"] >= 0, canc[f].any(axis=1)[np.maximum(a["pix_to_face"], 0)], False)
         assert d[~touch].max() <= 1e-5, d[~touch].max()
+
+
+S_TORCH_CPU = float.fromhex("0x1.bb67b0p+0")   # K[0][0] of the fixtures' FoV matrix: torch.tan on this container's CPU (+1 ulp of the double-rounded value)
+
+
+def test_oracle_projection_bmm_switch_reproduces_the_torch_restatement_on_coincident_shells(oracle):
+    """Switch #5 (round 6): the world -> view transform accumulated like a K = 4 matrix product (ascending k,
+    fused multiply-adds) — PyTorch3D's transform_points is a torch.bmm.  With the closed form the oracle and the torch restatement
+    of the CAD-like object disagree on 182 of 6 079 covered pixels, every one a swap between a face and its coincident reversed
+    twin (test above).  With the switch AND the fixture's own K[0][0] (torch's fp32 tan, +1 ulp) they agree on EVERY pixel: the twin
+    swaps were the projection's rounding sequence and nothing else.  Either ingredient alone leaves some."""
+    fx = _fx("torch_restatement_r5.npz")
+    v, f = syn.cad_mesh(int(fx["cad_seed"]), n_faces=int(fx["cad_faces"]))
+    S = int(fx["cad_image_size"])
+    want_map = fx["cad_pix_to_face"].astype(np.int32)
+    n_diff = {}
+    try:
+        for bmm in (False, True):
+            for s_over in (0.0, S_TORCH_CPU):
+                oracle.set_projection_bmm(bmm)
+                oracle.set_options(True, s_over)
+                got = oracle.render_meshes([v], [f], fx["cad_azim"][None], fx["cad_elev"][None], fx["cad_dist"][None], S,
+                                           obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, mode=1)
+                n_diff[(bmm, s_over > 0)] = int((got["pix_to_face"].reshape(want_map.shape) != want_map).sum())
+    finally:
+        oracle.set_projection_bmm(False)
+        oracle.set_options()
+    print("cad object, pixels on another face than the torch restatement (of %d covered): %s" % ((want_map >= 0).sum(), n_diff))
+    assert n_diff[(True, True)] == 0
+    assert n_diff[(False, False)] > 0 and n_diff[(True, False)] > 0 and n_diff[(False, True)] > 0
+
+
+def test_oracle_projection_bmm_switch_moves_only_coincident_twins(oracle):
+    """... and what the switch moves elsewhere: nothing on lumpy icospheres (two C2 objects x 12 views at 224 x 224: 0 pixels), only
+    face <-> coincident-twin swaps on CAD-like objects (seeds 0-2, 4 views, 128 x 128), colours elsewhere within 1e-5.  (Full C2
+    and 5 120-face CAD objects: tools/report_oracle_switches.py -> profiles/r06_oracle_switches.txt.)"""
+    def both(vl, fl, az, el, di, S):
+        out = []
+        for bmm in (False, True):
+            oracle.set_projection_bmm(bmm)
+            try:
+                out.append(oracle.render_meshes(vl, fl, az, el, di, S, obj_color=(0.99999,) * 3, bg_color=(0.99999,) * 3, mode=1))
+            finally:
+                oracle.set_projection_bmm(False)
+        return out
+    oracle.set_threads(8)
+    try:
+        az, el, di = syn.spherical_views(12)
+        vl, fl = zip(*[syn.synthetic_mesh("M", i) for i in range(2)])
+        a, b = both(list(vl), list(fl), np.tile(az, (2, 1)), np.tile(el, (2, 1)), np.tile(di, (2, 1)), 224)
+        assert int((a["pix_to_face"] != b["pix_to_face"]).sum()) == 0
+        assert np.abs(a["images"] - b["images"]).max() <= 1e-5
+        azc, elc, dic = (x[None] for x in syn.circular_views(4, 30.0, 2.2))
+        swaps = 0
+        for seed in range(3):
+            v, f = syn.cad_mesh(seed, n_faces=1280)
+            a, b = both([v], [f], azc, elc, dic, 128)
+            differ = a["pix_to_face"] != b["pix_to_face"]
+            twin_key = lambda i: tuple(sorted(map(tuple, v[f[i]].tolist())))   # noqa: E731
+            n_twin = sum(1 for x, y in zip(a["pix_to_face"][differ], b["pix_to_face"][differ]) if x >= 0 and y >= 0 and twin_key(x) == twin_key(y))
+            assert int(differ.sum()) == n_twin, (seed, int(differ.sum()), n_twin)
+            d = np.abs(a["images"] - b["images"])[0].max(axis=1)
+            assert d[~differ].max() <= 1e-5
+            swaps += n_twin
+        print("cad seeds 0-2: %d twin swaps" % swaps)
+        assert swaps > 0
+    finally:
+        oracle.set_threads(1)
