@@ -145,9 +145,10 @@ typedef struct mvr_points_params {
 } mvr_points_params;
 
 /* ABI generation of this header: bumped whenever a struct layout or an entry point's contract changes (101: fov_scale in
- * mvr_mesh_params, flag 64, 8-entry arrays of mvr_profile_end; 102: mvr_mesh_fast_stats).  mvr_version() returns the value the library was built with;
+ * mvr_mesh_params, flag 64, 8-entry arrays of mvr_profile_end; 102: mvr_mesh_fast_stats; 103: flag 128 = MVR_PROJECTION_FMA, the mesh workspace carries the exact settle's candidates inside the
+ * strips' list regions — mvr_mesh_workspace_bytes answers 30 % less, and a forward's workspace is not readable by a 102 backward).  mvr_version() returns the value the library was built with;
  * a loader must refuse a library whose value differs (mvtn_amd/_lib.py does). */
-#define MVR_ABI_VERSION 102
+#define MVR_ABI_VERSION 103
 int mvr_version(void);
 const char *mvr_last_error(void);
 /* Hash of the sources (and compiler flags) this library was built from, as mvtn_amd/build.py computes it: lets a loader

@@ -10,7 +10,7 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 _vp = ctypes.c_void_p
 
 MVR_OK = 0
-MVR_ABI_VERSION = 102   # == MVR_ABI_VERSION of include/mvr.h == mvr_version() of the library
+MVR_ABI_VERSION = 103   # == MVR_ABI_VERSION of include/mvr.h == mvr_version() of the library
 MVR_CULL_BACKFACES = 1
 MVR_PERSPECTIVE_CORRECT = 2
 MVR_WORKSPACE_FROM_FORWARD = 4

@@ -133,7 +133,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libmvr_hip.so does not export %s" % name
     assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
-    assert lib.mvr_version() == _lib.MVR_ABI_VERSION == 102
+    assert lib.mvr_version() == _lib.MVR_ABI_VERSION == 103
     # struct layouts agree with the header (sizes computed by hand from include/mvr.h)
     assert ctypes.sizeof(_lib.MeshBatch) == 6 * 4 + 5 * 8
     assert ctypes.sizeof(_lib.MeshParams) == 6 * 4 + 5 * 4 + 6 * 4 + 4 + 6 * 4 + 4 * 8 + 8

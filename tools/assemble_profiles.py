@@ -61,6 +61,8 @@ sq["k_points_raster_shade"] = pmc("%s/pmc_sq1_points_fwd" % src, "k_points_raste
 if glob.glob("%s/pmc_sq1_soft_fwdbwd/**/*counter_collection.csv" % src, recursive=True):
     for kern in ("k_mesh_soft_forward", "k_mesh_soft_backward("):
         sq[kern.rstrip("(")] = pmc("%s/pmc_sq1_soft_fwdbwd" % src, kern)
+if glob.glob("%s/pmc_sq1_geo_cad/**/*counter_collection.csv" % src, recursive=True):   # round 6: the CAD-like batch's forward
+    sq["k_mesh_raster_fast (CAD-like batch)"] = pmc("%s/pmc_sq1_geo_cad" % src, "k_mesh_raster_fast")
 if os.path.exists("%s/bench_driver_like.json" % src):
     shutil.copy("%s/bench_driver_like.json" % src, "%s/%s_bench_driver_like.json" % (dst, tag))
 sq["_note"] = ("rocprofv3 --pmc passes of tools/collect_profiles.sh (C3 step for the mesh kernels, C4 for the points kernel); SQ_*_CYCLES / "

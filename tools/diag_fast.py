@@ -58,6 +58,28 @@ bins8 = np.zeros(8)
 for x in srt:
     bins8[np.argmin(bins8)] += x
 print("  objects dealt to 8 XCDs heaviest-first onto the lightest XCD: max / mean %.3f (as launched: %.3f)" % (bins8.max() / bins8.mean(), xs.max() / xs.mean()))
+# occupancy over time per XCD (stamps of one XCD share a clock): how long does the launch run with fewer than half / a quarter of
+# its workgroup slots busy — the tail —, and when does the busiest period end?
+for x in range(8):
+    r = allr[x::8]
+    r = r[r[:, 5] > 0]
+    if not len(r):
+        continue
+    t0x = r[:, 0].min()
+    ev = np.concatenate([np.stack([r[:, 0] - t0x, np.ones(len(r))], 1), np.stack([r[:, 5] - t0x, -np.ones(len(r))], 1)])
+    ev = ev[np.argsort(ev[:, 0], kind="stable")]
+    occ = np.cumsum(ev[:, 1])
+    T = ev[-1, 0]
+    peak = occ.max()
+    below_half = ev[np.where(occ < 0.5 * peak)[0], 0]
+    below_half = below_half[below_half > 0.3 * T]
+    below_q = ev[np.where(occ < 0.25 * peak)[0], 0]
+    below_q = below_q[below_q > 0.3 * T]
+    dt = np.diff(ev[:, 0])
+    avg_occ = (occ[:-1] * dt).sum() / T
+    u = 0.01 if "MVR_DIAG_WALL" in os.environ.get("MVR_DIAG_EXTRA", "") else 1.0 / 2100.0   # microseconds per stamp unit (wall clock: 100 MHz; else ~2.1 GHz, NOT comparable across CUs)
+    print("XCD %d: span %.1f us, peak %d workgroups resident, mean %.1f (%.0f %% of the peak); occupancy below half of the peak from %.1f us (the last %.0f %% of the span), below a quarter from %.1f us" % (
+        x, T * u, peak, avg_occ, 100 * avg_occ / peak, (below_half.min() if len(below_half) else T) * u, 100 * (1 - (below_half.min() if len(below_half) else T) / T), (below_q.min() if len(below_q) else T) * u))
 t_first, t_last = allr[allr[:, 5] > 0, 0].min(), allr[:, 5].max()
 ends = np.array([allr[x::8, 5].max() - t_first for x in range(8)])
 print("kernel span by the stamps: %.0f cycles; last workgroup of each XCD ends at (k cycles): %s" % (t_last - t_first, " ".join("%.0f" % (e / 1e3) for e in ends)))
