@@ -115,7 +115,7 @@ struct ProfScope {
 };
 
 // Scheduling hints — wave priorities (s_setprio) in the mesh rasterisers, the start stagger (s_sleep) of the point rasteriser's first
-// resident batch: timing only, never results.  -DMVR_NO_TUNING compiles them out; tests/test_gpu_round5.py builds that variant and
+// resident batch: timing only, never results.  -DMVR_NO_TUNING compiles them out; tests/test_gpu_mesh_forward.py builds that variant and
 // checks that mesh and point renders at 128 / 224 / 448 pixels are bit-identical with and without them.
 #ifdef MVR_NO_TUNING
 #define MVR_SETPRIO(p) ((void)0)

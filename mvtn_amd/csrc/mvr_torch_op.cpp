@@ -8,7 +8,7 @@
 // No kernels and no arithmetic here: every call goes to the C ABI of include/mvr.h (libmvr_hip.so), through function addresses
 // that mvtn_amd/_lib.py hands over — this file does not link against the library, and the library stays free of torch types.
 // What the node does is what functional._RenderMeshViews does (same buffers, same saved tensors, same two library calls, same
-// fall-back when somebody also differentiates through the returned cameras); tests/test_gpu_round4.py compares the two bit for bit.
+// fall-back when somebody also differentiates through the returned cameras); tests/test_gpu_module.py compares the two bit for bit.
 #include <ATen/ATen.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>

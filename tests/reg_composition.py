@@ -2,7 +2,7 @@
 ops.py:138-146 + util.RandomHorizontalFlip / RandomCrop, util.py:168-242), spelled with plain torch ops and drawing from
 the generators in the reference's order.  Test infrastructure: pinned to the reference's own outputs on the CPU
 (tests/test_host_logic.py, fixture tests/golden/regularize_views.npz) and used as the expectation of the fused HIP pass on
-the GPU (tests/test_gpu_parity.py)."""
+the GPU (tests/test_gpu_mesh_forward.py)."""
 import warnings
 
 import torch

@@ -4,7 +4,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mvtn_amd import synthetic as syn
-import test_gpu_round4 as t4
+import gpu_helpers as t4   # (round 6: the helpers of the refiled GPU tests)
 fx = t4._fx("torch_restatement_grad.npz")
 S = int(fx["c3_image_size"])
 az, el, di = (fx["c3_" + k].astype(np.float32) for k in ("azim", "elev", "dist"))
