@@ -762,7 +762,19 @@ template <typename T, typename Mid = NoMid, bool FLAT = false> MVR_HD void phong
 #endif
   const T inv_s = trcp(cam.s);
   const T dx = px * inv_s, dy = py * inv_s;
+#ifndef MVR_BWD_K_DIFF
+#define MVR_BWD_K_DIFF 1
+#endif
+#if MVR_BWD_K_DIFF
+  // k_i = d . (v_j x v_k) = det[d, v_j, v_k] as the 2 x 2 determinant of the RAY-RELATIVE vectors a_i = v_i - z_i d (adding multiples of
+  // d to the other columns leaves the determinant alone; a_i.z = 0): the differences come first, as in the reference's edge functions,
+  // instead of three products of absolute view-space coordinates that cancel against each other when the face is nearly edge-on
+  const T a0x = fv.v0.x - fv.v0.z * dx, a0y = fv.v0.y - fv.v0.z * dy, a1x = fv.v1.x - fv.v1.z * dx, a1y = fv.v1.y - fv.v1.z * dy,
+          a2x = fv.v2.x - fv.v2.z * dx, a2y = fv.v2.y - fv.v2.z * dy;
+  const T k0 = a1x * a2y - a1y * a2x, k1 = a2x * a0y - a2y * a0x, k2 = a0x * a1y - a0y * a1x;
+#else
   const T k0 = (fv.n0.z + dx * fv.n0.x) + dy * fv.n0.y, k1 = (fv.n1.z + dx * fv.n1.x) + dy * fv.n1.y, k2 = (fv.n2.z + dx * fv.n2.x) + dy * fv.n2.y;
+#endif
   const T sum = (k0 + k1) + k2;
   const T r = sum != (T)0 ? trcp(sum) : (T)0;
   const T w0 = k0 * r, w1 = k1 * r, w2 = k2 * r;

@@ -241,35 +241,31 @@ def test_backward_kernels_against_torch_autograd_c3(gather):
         clean = err[~dirty].max()
         print("c3 %s (%s): max relative error %.2e over the %d views with identical maps (%.2e over the %d with a pixel on another face)" % (
             name, "gather" if gather else "table", clean, int((~dirty).sum()), err[dirty].max() if dirty.any() else 0.0, int(dirty.sum())))
-        # fp32 kernels against a float64 derivative: <= 3.3e-3 at one view, <= 1.5e-3 at a second, <= 4e-4 elsewhere.  Round 4
-        # blamed relu kinks of the diffuse term; round 5 measured it: NO covered pixel of this case has |n . l| < 1e-5 (the
-        # fixture counts them).  What the outliers are is the next test: a few dozen pixels on nearly edge-on faces.
-        assert clean <= 5e-3, (name, clean)
-        assert (err[~dirty] > 2e-3).sum() <= 2, (name, err)
-        assert err.max() <= 3e-2, (name, err.max())
+        # fp32 kernels against a float64 derivative.  Rounds 4-5: <= 3.3e-3 at one view, <= 1.5e-3 at a second, <= 4e-4 elsewhere
+        # (round 4 blamed relu kinks of the diffuse term; round 5 measured it: NO covered pixel of this case has |n . l| < 1e-5 —
+        # the outliers are a few dozen pixels on nearly edge-on faces, next test).  Round 6: the barycentrics of the backward from
+        # the RAY-RELATIVE vectors v_i - z_i d (differences first, as in the reference's edge functions) instead of the cross products
+        # v_j x v_k of absolute view-space coordinates: <= 1.3e-3 at the two outlier views, <= 1.2e-4 elsewhere.
+        assert clean <= 2e-3, (name, clean)
+        assert err.max() <= 5e-3, (name, err.max())
     # Round 6: the same losses differentiated by torch.autograd in FLOAT32 — the arithmetic the reference
-    # itself runs (tests/golden/make_torch_restatement_grad32.py) — beside the float64 fixture.  What the comparison shows
-    # (tools/r06_c3_err.py prints all 72 derivatives): float32 autograd has the SAME outliers — (object 0, view 9) and (object 1,
-    # view 3), the views with pixels on nearly edge-on faces, are its two worst views for every parameter as they are the
-    # library's — at 1.1e-3 / 5.9e-4 (azim) where the library has 2.6e-3 / 1.0e-3; over all derivatives the library's error is
-    # 2-5 x float32 autograd's (mean 2.2e-4 vs 7.8e-5 for azim, 2.6e-4 vs 5.3e-5 for dist).  The verdict's proposed bound
-    # |library - f64| <= 2 |torch f32 - f64| + 2e-4 holds for 66 of the 69 derivatives of views with identical maps, not for all:
-    # asserted are the measured form (6 x + 4e-4 everywhere), the count, and that the worst views coincide.
+    # itself runs (tests/golden/make_torch_restatement_grad32.py) — beside the float64 fixture.  float32 autograd has the SAME two
+    # outlier views — (object 0, view 9) and (object 1, view 3): 1.1e-3 / 5.9e-4 of the largest azim derivative — and the library
+    # (since its barycentrics come from the ray-relative vectors) sits beside it: 1.2e-3 / 8.9e-4, means 9.4e-5 vs 7.7e-5 azim,
+    # 4.0e-5 vs 3.2e-5 elev, 6.1e-5 vs 5.2e-5 dist (with the cross-product form of rounds 2-5: 2.6e-3 / 1.0e-3, means 2-5 x torch's,
+    # and 3 of 69 derivatives beyond the bound).  Asserted, per derivative of every view with an identical map, the verdict's bound:
+    # |library - f64| <= 2 |torch f32 - f64| + 2e-4 of the largest derivative.  (tools/r06_c3_err.py prints all 72.)
     f32 = _fx("torch_restatement_grad32.npz")
-    n_viol = 0
     for name, got in zip(("azim", "elev", "dist"), grads):
         ref = fx["c3_grad_" + name].astype(np.float64)
         scale = np.abs(ref).max()
         e_lib = np.where(dirty, 0.0, np.abs(got - ref) / scale)
         e_t32 = np.where(dirty, 0.0, np.abs(f32["c3_grad_%s_f32" % name] - ref) / scale)
         viol = ~(e_lib <= 2.0 * e_t32 + 2e-4)
-        n_viol += int(viol.sum())
         print("c3 %s (%s): |library - f64| max %.2e mean %.2e, |torch f32 - f64| max %.2e mean %.2e (relative to the largest derivative); beyond 2 x + 2e-4 at %s" % (
             name, "gather" if gather else "table", e_lib.max(), e_lib.mean(), e_t32.max(), e_t32.mean(), [tuple(int(x) for x in ij) for ij in np.argwhere(viol)]))
-        assert (e_lib <= 6.0 * e_t32 + 4e-4).all(), (name, e_lib, e_t32)
-        if name != "elev":   # (elev: both sides' outliers are below 6e-4, their order is noise)
-            assert set(np.argsort(e_lib.reshape(-1))[-2:]) == set(np.argsort(e_t32.reshape(-1))[-2:]), (name, e_lib, e_t32)
-    assert n_viol <= 6, n_viol
+        assert not viol.any(), (name, e_lib, e_t32)
+        assert e_lib.mean() <= 2.0 * e_t32.mean(), (name, e_lib.mean(), e_t32.mean())
 
 
 @pytest.mark.parametrize("gather", [False, True], ids=["table_kernel", "gather_kernel"])
@@ -279,7 +275,8 @@ def test_backward_outliers_are_the_pixels_of_edge_on_faces(gather):
     |2 x NDC area| > t: nearly edge-on, the barycentrics' derivative ~ 1 / area — and torch.autograd's gradients of the loss WITHOUT
     those pixels.  With the same mask on the upstream gradient the fp32 kernels agree with float64 autograd to <= 2e-4 on every
     derivative of every view with an identical pixel -> face map once the 40 pixels with cond > 100 (0.008 % of the covered
-    ones) are out; with only the 4 pixels of cond > 300 out, 7 derivatives still miss 2e-4; with 1 pixel out, 12.  (And no
+    ones) are out (round 6, ray-relative barycentrics: <= 1.5e-4, and already with only the 4 pixels of cond > 300 out; with 1 pixel
+    out 2 derivatives miss 2e-4.  Rounds 4-5, cross-product form: 7 with 4 pixels out, 12 with 1).  (And no
     pixel sits on a kink of relu(n . l): `c3_kink_bits` is empty, the masked and unmasked gradients are equal bit for bit.)"""
     fx = _fx("torch_restatement_grad.npz")
     if "c3_cond_bits" not in fx:
@@ -304,7 +301,7 @@ def test_backward_outliers_are_the_pixels_of_edge_on_faces(gather):
             t, mask.sum(), over[t], 3 * (~dirty).sum(), err[:, ~dirty].max(), err[:, dirty].max()))
         if t <= 100.0:
             assert over[t] == 0 and err[:, dirty].max() <= 2e-3, (t, err)
-    assert over[1000.0] >= over[300.0] > 0     # the fewer of those pixels are masked, the more derivatives miss the bound
+    assert over[1000.0] >= over[300.0] >= over[100.0]     # the fewer of those pixels are masked, the more derivatives miss the bound
 
 
 def test_cad_batch_through_the_module_and_backward(oracle):

@@ -755,7 +755,7 @@ def test_hip_against_torch_restatement_on_cad_and_ragged_meshes(oracle):
         ref = fx["cad_grad_" + name].astype(np.float64)
         rel = np.abs(got[k] - ref).max() / np.abs(ref).max()
         print("cad %s: max relative error %.2e against torch.autograd on the fixture's map (the library's own map differs at %d twin pixels)" % (name, rel, n_diff))
-        assert rel <= 5e-3, (name, rel, got[k], ref)
+        assert rel <= 2e-3, (name, rel, got[k], ref)   # (observed: 8.0e-4 / 3.0e-4 / 4.7e-4)
     # Round 6: beside float32 torch.autograd on the same map (make_torch_restatement_grad32.py) — per
     # derivative the library is off the float64 value by at most twice what the reference's own fp32 arithmetic is, + 2e-4
     f32 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "torch_restatement_grad32.npz"))
