@@ -42,6 +42,7 @@ for case in range(n_cases):
     di = rng.uniform(0.9, 3.0, (B, V)).astype(np.float32)
     obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
     zc = 0.5 if (persp and rng.integers(0, 2)) else 0.0   # PyTorch3D >= 0.5's face clipping (cuts faces when dist < ~1.5)
+    fma = bool(rng.integers(0, 4) == 0)   # round 6: MVR_PROJECTION_FMA against the oracle's switch #5 (decides coincident twins)
     if case < first_case:
         continue
     # The oracle's default vertex-normal sums are the reference's form (a float index_add in face order).  Only where a mesh has
@@ -49,27 +50,29 @@ for case in range(n_cases):
     # order, the library's order-independent sums give exactly 0) the oracle sums as the library does (switch #4) — ADVICE r5.
     exact_sum = any(bool(oracle.cancelled_normal_vertices(v_, f_).any()) for v_, f_ in zip(vl, fl))
     oracle.set_normals_exact_sum(exact_sum)
+    oracle.set_projection_bmm(fma)
     want = oracle.render_meshes(vl, fl, az, el, di, size, obj_color=obj, bg_color=bg, perspective_correct=persp, cull_backfaces=cull, mode=1,
                                 z_clip=zc)
+    oracle.set_projection_bmm(False)
     packed = PackedMeshes.from_meshes(Meshes(vl, fl), dev)
     t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
     R, T = F.look_at_view_transform(t(di.reshape(-1)), t(el.reshape(-1)), t(az.reshape(-1)))
-    params = F.mesh_params(V, size, 1, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip, z_clip=zc)
+    params = F.mesh_params(V, size, 1, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip, z_clip=zc, projection_fma=fma)
     img, p2f = F.render_meshes_fragments(packed, R, T, t([[0, 1, 0]]), params)
     p2f = p2f.cpu().numpy(); img = img.cpu().numpy()
     nd = int((p2f != want["pix_to_face"]).sum())
     err = float(np.abs(img - want["images"]).max())
     flag = "" if nd == 0 else "  <-- COVERAGE MISMATCH"
     bad += nd != 0
-    print("case %2d: B=%d V=%d size=%3d strip=%d persp=%d cull=%d zclip=%.1f cut=%d faces=%s covered=%.2f  map diffs %d  max|d| %.2e%s"
-          % (case, B, V, size, strip, persp, cull, zc, int(want["straddlers"].sum()), [len(f) for f in fl], (p2f >= 0).mean(), nd, err, flag))
+    print("case %2d: B=%d V=%d size=%3d strip=%d persp=%d cull=%d zclip=%.1f fma=%d cut=%d faces=%s covered=%.2f  map diffs %d  max|d| %.2e%s"
+          % (case, B, V, size, strip, persp, cull, zc, fma, int(want["straddlers"].sum()), [len(f) for f in fl], (p2f >= 0).mean(), nd, err, flag))
     # the two backward kernels (face table / per-pixel gathers) on the same case: same arithmetic, different summation order
     if case % 4 == 0:
         G = torch.randn(B, V, 3, size, size, generator=torch.Generator().manual_seed(case)).to(dev)
         grads = []
         for gather in (False, True):
             pb = F.mesh_params(V, size, B * V, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip, z_clip=zc,
-                               gather_backward=gather)
+                               gather_backward=gather, projection_fma=fma)
             Rg, Tg = R.detach().clone().requires_grad_(True), T.detach().clone().requires_grad_(True)
             Lg = F.camera_position_from_spherical_angles(t(di.reshape(-1)), t(el.reshape(-1)), t(az.reshape(-1))).detach().requires_grad_(True)
             F.render_meshes(packed, Rg, Tg, Lg, pb).backward(G)
