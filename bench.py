@@ -197,19 +197,40 @@ def measure_secondary(name, dev, lib, H, steps, untimed, with_oracle, rotation_c
         with torch.no_grad():
             return renderer(packed, points, azim, elev, dist_t)[0]
 
-    # untimed: at least `untimed` steps AND at least 60 ms of them — the GPU idles while the host builds a workload's inputs and its
+    # untimed: at least `untimed` steps AND at least 250 ms of them — the GPU idles while the host builds a workload's inputs and its
     # clocks come back up only after some milliseconds of load: 100 steps of the 55-us point step (5 ms) read 8 us per step slow
+    import gc
+    gc.collect()      # (the previous workloads' garbage — meshes, fixtures, oracle buffers — is collected here, not inside the timed region)
+    torch.cuda.empty_cache()   # ... and their device blocks go back to the driver: this workload's buffers are allocated as in a process of its own
     n_untimed, t_w = 0, time.perf_counter()
-    while n_untimed < untimed or time.perf_counter() - t_w < 0.06:
+    # (the results of the steps are dropped at once, as in the headline's timed() region: every step then writes the SAME output block.
+    # It matters for C4 only: its 240 MB of views fit the 256 MB Infinity Cache once, not twice — with two blocks alternating
+    # (`out = render()` in the loop) the point step reads 62 us instead of 55; C2's 116 MB fit twice)
+    while n_untimed < untimed or time.perf_counter() - t_w < 0.25:
         for _ in range(50):
-            out = render()
+            render()
         torch.cuda.synchronize()
         n_untimed += 50
+    gc_was_on = gc.isenabled()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = render()
+        render()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
+    out = render()
+    # the host's share of a step (Python + dispatch + launches), measured with a short queue: 4 x 25 steps, each group behind a synchronize
+    host_s = 0.0
+    for _ in range(4):
+        torch.cuda.synchronize()
+        render()
+        t1 = time.perf_counter()
+        for _ in range(25):
+            render()
+        host_s += time.perf_counter() - t1
+    torch.cuda.synchronize()
     # kernel durations: HIP events on the launch stream (library-side), the same number of steps; the mesh pre-pass in a pass of its own
     kind = 1 if workload == "points_fwd" else 0
     ms, cnt = (ctypes.c_double * 8)(), (ctypes.c_int32 * 8)()
@@ -221,7 +242,7 @@ def measure_secondary(name, dev, lib, H, steps, untimed, with_oracle, rotation_c
     kern_ms = ms[kind] / max(1, cnt[kind])
     alg = algorithmic_bytes("mesh_fwd" if workload == "mesh_fwdbwd" else workload, B, V, H, W, nv_list, nf_list, P)
     res = {"workload": "%s: B=%d x %d views, %dx%d%s" % (workload, B, V, H, W, "" if workload == "points_fwd" else ", geometry %s, tier %s" % (geometry, tier)),
-           "value": B * V * steps / elapsed, "unit": "views/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "untimed_steps": n_untimed,
+           "value": B * V * steps / elapsed, "unit": "views/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "untimed_steps": n_untimed, "host_enqueue_ms_per_step": host_s / 100 * 1e3,
            "kernel": "k_points_raster_shade" if workload == "points_fwd" else "k_mesh_raster_fast", "kernel_ms": kern_ms,
            "algorithmic_bytes_per_launch": alg, "frac": (alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms > 0 else None}
     if workload == "mesh_fwdbwd":
@@ -735,7 +756,8 @@ def main():
         secondary = {}
         del out
         t_sec = time.perf_counter()
-        for nm in SECONDARY:
+        only = [x for x in os.environ.get("MVR_BENCH_SECONDARY", "").split(",") if x]   # (developer aid: a subset, in the given order)
+        for nm in (only or SECONDARY):
             try:
                 secondary[nm] = measure_secondary(nm, dev, lib, H, max(1, args.secondary_steps), 100, not args.no_cpu_baseline, args.rotation_check)
             except Exception as exc:   # (a failure here must not lose the headline)
