@@ -80,6 +80,8 @@ for x in range(8):
     u = 0.01 if "MVR_DIAG_WALL" in os.environ.get("MVR_DIAG_EXTRA", "") else 1.0 / 2100.0   # microseconds per stamp unit (wall clock: 100 MHz; else ~2.1 GHz, NOT comparable across CUs)
     print("XCD %d: span %.1f us, peak %d workgroups resident, mean %.1f (%.0f %% of the peak); occupancy below half of the peak from %.1f us (the last %.0f %% of the span), below a quarter from %.1f us" % (
         x, T * u, peak, avg_occ, 100 * avg_occ / peak, (below_half.min() if len(below_half) else T) * u, 100 * (1 - (below_half.min() if len(below_half) else T) / T), (below_q.min() if len(below_q) else T) * u))
+if os.environ.get("MVR_DIAG_DUMP"):   # start / end stamps of every workgroup (blockIdx order) for offline scheduling simulations
+    np.save(os.environ["MVR_DIAG_DUMP"], allr)
 t_first, t_last = allr[allr[:, 5] > 0, 0].min(), allr[:, 5].max()
 ends = np.array([allr[x::8, 5].max() - t_first for x in range(8)])
 print("kernel span by the stamps: %.0f cycles; last workgroup of each XCD ends at (k cycles): %s" % (t_last - t_first, " ".join("%.0f" % (e / 1e3) for e in ends)))
