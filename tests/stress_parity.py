@@ -58,9 +58,17 @@ for case in range(n_cases):
     t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)
     R, T = F.look_at_view_transform(t(di.reshape(-1)), t(el.reshape(-1)), t(az.reshape(-1)))
     params = F.mesh_params(V, size, 1, obj, bg, perspective_correct=persp, cull_backfaces=cull, strip_rows=strip, z_clip=zc, projection_fma=fma)
-    img, p2f = F.render_meshes_fragments(packed, R, T, t([[0, 1, 0]]), params)
+    img, p2f, st4 = F.render_meshes_fragments(packed, R, T, t([[0, 1, 0]]), params, return_stats=True)
     p2f = p2f.cpu().numpy(); img = img.cpu().numpy()
     nd = int((p2f != want["pix_to_face"]).sum())
+    if nd:   # what differs: view, pixel, the two faces, whether they are coincident twins (same three positions); the fast rasteriser's statistics
+        st4 = [int(x) for x in st4.cpu()]
+        print("         fast-raster stats (strips redone, settle candidates, whole-wave entries, list entries):", st4)
+        for n_, y_, x_ in np.argwhere(p2f != want["pix_to_face"])[:12]:
+            b_ = n_ // V
+            g_, w_ = int(p2f[n_, y_, x_]), int(want["pix_to_face"][n_, y_, x_])
+            key = lambda i: tuple(sorted(map(tuple, vl[b_][fl[b_][i]].tolist()))) if i >= 0 else None   # noqa: E731
+            print("         view %d (mesh %d) pixel (%d, %d): library face %d, oracle face %d, coincident twins: %s" % (n_, b_, y_, x_, g_, w_, key(g_) == key(w_)))
     err = float(np.abs(img - want["images"]).max())
     flag = "" if nd == 0 else "  <-- COVERAGE MISMATCH"
     bad += nd != 0

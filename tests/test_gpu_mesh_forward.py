@@ -798,6 +798,28 @@ def test_untrusted_face_over_the_left_image_border(oracle):
         assert st[1] > 0                                           # its pixels went through the exact settle
 
 
+def test_untrusted_face_whose_affine_depth_extrapolates_negative(oracle):
+    """Round 6, found by tests/stress_parity.py (seed 41, case 61760 of 130 000; inputs in tests/golden/stress_case_61760.npz, written by
+    the stress script's own draws): a 96-face soup of double-sided quads 0.9 units from the camera.  One pair of coincident slivers
+    there is seen almost edge-on: not trusted (infinite tolerance), and the affine inverse depth of such a face extrapolates to a
+    NEGATIVE value at pixels it covers.  The bits of a negative float have bit 63 of the key set — the mark of an EXACT key — so the
+    settle took the sliver that held the pixel for already evaluated, and its twin (evaluated, the reference's loser) kept six
+    pixels.  Latent since round 5 (strips with more than 2 candidates per pixel fell back to the exact body then; round 6 gave such
+    strips room).  Untrusted faces now carry the constant plane iz~ = 1, trusted ones are guaranteed a positive affine value.
+    Maps bit-exact against the oracle in every strip height the fast path takes."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stress_case_61760.npz"))
+    vl, fl = [d["v0"], d["v1"]], [d["f0"], d["f1"]]
+    az, el, di, S = d["az"], d["el"], d["di"], int(d["size"])
+    exact, default, touch = _oracle_both_normal_sums(oracle, vl, fl, az, el, di, S, z_clip=0.0)
+    assert (exact["pix_to_face"][1] == 46).sum() >= 6          # the sliver the flaw lost
+    for strip in (0, 4, 8, 16, 32):
+        kw = dict(strip_rows=strip) if strip else {}
+        img, p2f, st = _render(vl, fl, az, el, di, S, z_clip=0.0, **kw)
+        assert (p2f != exact["pix_to_face"]).sum() == 0, strip
+        assert np.abs(img - exact["images"]).max() <= 1e-4, strip
+        assert st[1] > 0, st                                      # the settle ran
+
+
 @pytest.mark.parametrize("size,strip,layers,redone", [(224, 0, 2, False), (224, 0, 6, True), (256, 16, 2, True), (256, 8, 2, False)])
 def test_stacks_of_coincident_faces_fill_the_candidate_area(oracle, size, strip, layers, redone):
     """`layers` copies of one nearly frame-filling quad on top of each other, every second one with reversed winding (the (z, face index) tie
