@@ -730,26 +730,23 @@ template <typename T, typename Mid = NoMid> MVR_HD void phong_pixel_bwd_pre(cons
 
 // The perspective-correct case in RAY form.  The perspective-correct barycentrics of pixel (px, py) are the barycentrics
 // of the point where its ray d = (px / s, py / s, 1) meets the face's plane in VIEW space (bary_ray above):
-//     w_i = c_i / (c_0 + c_1 + c_2),  c_0 = d . (v1 x v2), c_1 = d . (v2 x v0), c_2 = d . (v0 x v1)
-// with the cross products a per-FACE constant, and their gradient goes to the view-space vertices directly:
-//     h_i = (dL/dw_i - sum_j dL/dw_j w_j) / sum c ;  dL/dv0 = d x (h1 v2 - h2 v1), dL/dv1 = d x (h2 v0 - h0 v2), dL/dv2 = d x (h0 v1 - h1 v0)
+//     w_i = k_i / (k_0 + k_1 + k_2),  k_0 = d . (v1 x v2), k_1 = d . (v2 x v0), k_2 = d . (v0 x v1)
+// (evaluated as 2 x 2 determinants of ray-relative vectors, below), and their gradient goes to the view-space vertices directly:
+//     h_i = (dL/dw_i - sum_j dL/dw_j w_j) / sum k ;  dL/dv0 = d x (h1 v2 - h2 v1), dL/dv1 = d x (h2 v0 - h0 v2), dL/dv2 = d x (h0 v1 - h1 v0)
 // — no projected vertices, no edge functions, no division by a vertex depth (finite for vertices at or behind the camera
 // plane): ~55 operations per pixel where the projected form (phong_pixel_bwd_pre) spends ~125 on the same two steps.  The
 // kEps clamps of the forward's quotients are not reproduced (they act on faces the rasteriser culls); a ray parallel to
-// the face's plane (sum c = 0) contributes nothing.
-template <typename T> struct FaceView { V3<T> v0, v1, v2, n0, n1, n2; };   // view-space vertices; n0 = v1 x v2, n1 = v2 x v0, n2 = v0 x v1
+// the face's plane (sum k = 0) contributes nothing.
+template <typename T> struct FaceView { V3<T> v0, v1, v2; };   // view-space vertices (rounds 3-5 also carried their cross products: the barycentrics' old form)
 template <typename T> MVR_HD FaceView<T> face_view_for_bwd(const PixelGradIn<T> &cam, const V3<T> &X0, const V3<T> &X1, const V3<T> &X2) {
 #if defined(__clang__)
 #pragma clang fp contract(fast)
 #endif
   FaceView<T> f;
   f.v0 = world_to_view(cam.R, cam.Tr, X0); f.v1 = world_to_view(cam.R, cam.Tr, X1); f.v2 = world_to_view(cam.R, cam.Tr, X2);
-  f.n0 = {f.v1.y * f.v2.z - f.v1.z * f.v2.y, f.v1.z * f.v2.x - f.v1.x * f.v2.z, f.v1.x * f.v2.y - f.v1.y * f.v2.x};
-  f.n1 = {f.v2.y * f.v0.z - f.v2.z * f.v0.y, f.v2.z * f.v0.x - f.v2.x * f.v0.z, f.v2.x * f.v0.y - f.v2.y * f.v0.x};
-  f.n2 = {f.v0.y * f.v1.z - f.v0.z * f.v1.y, f.v0.z * f.v1.x - f.v0.x * f.v1.z, f.v0.x * f.v1.y - f.v0.y * f.v1.x};
   return f;
 }
-// (`mid` as in phong_pixel_bwd_pre: fv.n* and X, N are read before it, X, N and fv.v* after it)
+// (`mid` as in phong_pixel_bwd_pre: a scheduling hook between the shading half and the geometric half)
 // FLAT (constant object colour): a term common to the three dL/dw_i cancels in h_i when the barycentrics sum to one, and the
 // texel's contribution dot(g_tex, c) is such a term — it is left out, with the texel's interpolation (phong_shade_bwd).
 template <typename T, typename Mid = NoMid, bool FLAT = false> MVR_HD void phong_pixel_bwd_ray(const PixelGradIn<T> &cam, T px, T py, const FaceView<T> &fv,
@@ -762,19 +759,12 @@ template <typename T, typename Mid = NoMid, bool FLAT = false> MVR_HD void phong
 #endif
   const T inv_s = trcp(cam.s);
   const T dx = px * inv_s, dy = py * inv_s;
-#ifndef MVR_BWD_K_DIFF
-#define MVR_BWD_K_DIFF 1
-#endif
-#if MVR_BWD_K_DIFF
   // k_i = d . (v_j x v_k) = det[d, v_j, v_k] as the 2 x 2 determinant of the RAY-RELATIVE vectors a_i = v_i - z_i d (adding multiples of
   // d to the other columns leaves the determinant alone; a_i.z = 0): the differences come first, as in the reference's edge functions,
   // instead of three products of absolute view-space coordinates that cancel against each other when the face is nearly edge-on
   const T a0x = fv.v0.x - fv.v0.z * dx, a0y = fv.v0.y - fv.v0.z * dy, a1x = fv.v1.x - fv.v1.z * dx, a1y = fv.v1.y - fv.v1.z * dy,
           a2x = fv.v2.x - fv.v2.z * dx, a2y = fv.v2.y - fv.v2.z * dy;
   const T k0 = a1x * a2y - a1y * a2x, k1 = a2x * a0y - a2y * a0x, k2 = a0x * a1y - a0y * a1x;
-#else
-  const T k0 = (fv.n0.z + dx * fv.n0.x) + dy * fv.n0.y, k1 = (fv.n1.z + dx * fv.n1.x) + dy * fv.n1.y, k2 = (fv.n2.z + dx * fv.n2.x) + dy * fv.n2.y;
-#endif
   const T sum = (k0 + k1) + k2;
   const T r = sum != (T)0 ? trcp(sum) : (T)0;
   const T w0 = k0 * r, w1 = k1 * r, w2 = k2 * r;
@@ -785,18 +775,19 @@ template <typename T, typename Mid = NoMid, bool FLAT = false> MVR_HD void phong
   if (!FLAT) { gw0 += dot_c(g_tex, c0); gw1 += dot_c(g_tex, c1); gw2 += dot_c(g_tex, c2); }
   const T gs = (gw0 * w0 + gw1 * w1) + gw2 * w2;
   const T h0 = (gw0 - gs) * r, h1 = (gw1 - gs) * r, h2 = (gw2 - gs) * r;
-  const V3<T> v0 = fv.v0, v1 = fv.v1, v2 = fv.v2;
-  const V3<T> Y0 = {h1 * v2.x - h2 * v1.x, h1 * v2.y - h2 * v1.y, h1 * v2.z - h2 * v1.z};
-  const V3<T> Y1 = {h2 * v0.x - h0 * v2.x, h2 * v0.y - h0 * v2.y, h2 * v0.z - h0 * v2.z};
-  const V3<T> Y2 = {h0 * v1.x - h1 * v0.x, h0 * v1.y - h1 * v0.y, h0 * v1.z - h1 * v0.z};
-  auto vert = [&](const V3<T> &Y, const V3<T> &Xw) {   // d x Y with d = (dx, dy, 1), then R / T through Xv = Xw R + T
-    const T gx = dy * Y.z - Y.y, gy = Y.x - dx * Y.z, gz = dx * Y.y - dy * Y.x;
+  auto add_vert = [&](const T gx, const T gy, const T gz, const V3<T> &Xw) {   // R / T through Xv = Xw R + T
     acc[0] += Xw.x * gx; acc[1] += Xw.x * gy; acc[2] += Xw.x * gz;
     acc[3] += Xw.y * gx; acc[4] += Xw.y * gy; acc[5] += Xw.y * gz;
     acc[6] += Xw.z * gx; acc[7] += Xw.z * gy; acc[8] += Xw.z * gz;
     acc[9] += gx; acc[10] += gy; acc[11] += gz;
   };
-  vert(Y0, X0); vert(Y1, X1); vert(Y2, X2);
+  // d L / d v_i = d x Y_i with Y_0 = h1 v2 - h2 v1 (cyclic).  d x v_i = d x a_i (v_i = a_i + z_i d and d x d = 0), and with a_i.z = 0,
+  // d = (dx, dy, 1): d x a_i = (-a_iy, a_ix, dx a_iy - dy a_ix) =: c_i — two operations per vertex instead of a cross product of
+  // absolute coordinates, and the gradient is h_j c_k - h_k c_j: 24 operations where Y_i and d x Y_i took 36, on the small vectors.
+  const T c0z = dx * a0y - dy * a0x, c1z = dx * a1y - dy * a1x, c2z = dx * a2y - dy * a2x;
+  add_vert(h2 * a1y - h1 * a2y, h1 * a2x - h2 * a1x, h1 * c2z - h2 * c1z, X0);
+  add_vert(h0 * a2y - h2 * a0y, h2 * a0x - h0 * a2x, h2 * c0z - h0 * c2z, X1);
+  add_vert(h1 * a0y - h0 * a1y, h0 * a1x - h1 * a0x, h0 * c1z - h1 * c0z, X2);
   acc[12] += g_cc.x; acc[13] += g_cc.y; acc[14] += g_cc.z;
   acc[15] += g_l.x; acc[16] += g_l.y; acc[17] += g_l.z;
 }

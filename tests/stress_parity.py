@@ -1,6 +1,9 @@
 """Manual stress run (not collected by pytest): random meshes / views / image sizes / strip heights through the C ABI
 against the oracle — bit-exact pixel->face maps, pixel tolerance on well-conditioned pixels.
-    python tests/stress_parity.py [n_cases] [seed] [first_case]      (first_case: the cases before it are only drawn, not run)"""
+    python tests/stress_parity.py [n_cases] [seed] [first_case] [close]    (first_case: the cases before it are only drawn, not run;
+    close: round 6 — CAD-like soups and assemblies only, camera 0.9-1.4 units away, no clip plane, small images: many faces seen
+    edge-on or reaching behind the camera plane, i.e. untrusted faces and strips with several candidates per pixel — the corner
+    where case 61760 of seed 41 was found)"""
 import os
 import sys
 
@@ -17,6 +20,7 @@ from mvtn_amd.structures import Meshes, PackedMeshes  # noqa: E402
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+close = len(sys.argv) > 4 and sys.argv[4] == "close"
 dev = torch.device("cuda:0")
 oracle.set_threads(8)
 bad = 0
@@ -29,7 +33,16 @@ for case in range(n_cases):
     vl, fl = [], []
     for b in range(B):
         kind = rng.integers(0, 6)
-        if kind == 0:
+        if close:
+            kind = (0, 4, 6)[int(rng.integers(0, 3))]
+        if kind == 6:   # a STACK: 2-4 copies of a soup on top of each other (own vertices, random winding and vertex rotation per face):
+            v0_, f0_ = syn.cad_soup(int(rng.integers(0, 1000)), n_quads=int(rng.integers(4, 20)))   # several candidates per pixel
+            nc = int(rng.integers(2, 5))
+            v = np.concatenate([v0_] * nc, 0)
+            f = np.concatenate([f0_ + k * len(v0_) for k in range(nc)], 0)
+            f = np.stack([np.roll(t_[::-1] if rng.integers(0, 2) else t_, int(rng.integers(0, 3))) for t_ in f], 0)
+            f = f[rng.permutation(len(f))]
+        elif kind == 0:
             v, f = syn.cad_soup(int(rng.integers(0, 1000)))
         elif kind >= 4:   # round 5: CAD-like assemblies (big flat triangles, slivers, coincident reversed shells, interior parts)
             v, f = syn.cad_mesh(int(rng.integers(0, 1000)), n_faces=int(rng.choice([320, 1280, 5120])), double_sided=float(rng.choice([0.0, 0.3, 0.6])))
@@ -42,6 +55,10 @@ for case in range(n_cases):
     di = rng.uniform(0.9, 3.0, (B, V)).astype(np.float32)
     obj, bg = (0.9, 0.8, 0.7), (0.1, 0.2, 0.3)
     zc = 0.5 if (persp and rng.integers(0, 2)) else 0.0   # PyTorch3D >= 0.5's face clipping (cuts faces when dist < ~1.5)
+    if close:
+        size = int(rng.choice([32, 45, 64, 64, 96, 128]))
+        di = rng.uniform(0.9, 1.4, (B, V)).astype(np.float32)
+        zc = 0.0
     fma = bool(rng.integers(0, 4) == 0)   # round 6: MVR_PROJECTION_FMA against the oracle's switch #5 (decides coincident twins)
     if case < first_case:
         continue
